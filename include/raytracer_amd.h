@@ -1,0 +1,266 @@
+/*
+ * raytracer_amd.h - C ABI of the MI355X path-tracing hot path.
+ *
+ * The reference (nickolas-pohilets/RayTracer) has no FFI of its own: its seam is
+ * "Swift scene API -> C structs shared with the kernel -> kernel argument table"
+ * (MetalRayTracer/Renderable.h, Materials.h, Config.h; SceneBuffers.swift;
+ * ContentView.swift Renderer).  This header is that seam as a C ABI: the records
+ * keep the reference's field names, meaning and enum values; simd vector types
+ * are spelled as plain float arrays and Metal handles as 32-bit ids.
+ *
+ * Conventions
+ *  - every function returns >= 0 on success (an id where documented) and a
+ *    negative RT_ERR_* code on failure; rt_last_error() then describes it.
+ *    Nothing throws or aborts across the boundary (the reference crashes on
+ *    `!`/precondition, e.g. SceneBuffers.swift:21,50).
+ *  - records passed to rt_add_* / rt_shape_* are copied; the caller may free them
+ *    at once (the reference copies into device buffers too,
+ *    SceneBuffers.swift:92-101).
+ *  - pointers named *_dev are DEVICE pointers owned by the caller; `stream` is a
+ *    hipStream_t passed as void* (NULL = default stream).  Calls that take a
+ *    stream are asynchronous with respect to the host.
+ *  - one host thread per scene; calls on one scene are serialised by the caller.
+ */
+#ifndef RAYTRACER_AMD_H
+#define RAYTRACER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,      /* bad argument / id / record */
+    RT_ERR_STATE = -2,        /* scene not committed, or already committed */
+    RT_ERR_LIMIT = -3,        /* a documented limit was exceeded */
+    RT_ERR_DEVICE = -4,       /* HIP runtime error */
+};
+
+/* ---- geometry records: MetalRayTracer/Renderable.h:13-63 ------------------- */
+
+/* Renderable.h:13-16.  rotation is column-major (rotation[3*c + r] = columns[c][r]). */
+typedef struct { float rotation[9]; float translation[3]; } RtTransform;
+
+/* Renderable.h:18-25 */
+typedef struct { RtTransform transform; float radius; size_t material_offset; } RtSphere;
+
+/* Renderable.h:27-37: local frame has the axis on +y and the base at the origin. */
+typedef struct {
+    RtTransform transform;
+    float radius, height;
+    size_t bottom_material_offset, top_material_offset, side_material_offset;
+} RtCylinder;
+
+/* Renderable.h:39-52: box [0,size] in the local frame. */
+enum RtFace { rt_face_left, rt_face_right, rt_face_bottom, rt_face_top, rt_face_back, rt_face_front };
+typedef struct { RtTransform transform; float size[3]; size_t material_offset[6]; } RtCuboid;
+
+/* Renderable.h:54-63: w = n/|n|^2, normal = n/|n|, d = dot(origin, normal), n = cross(u, v)
+ * (Primitives.swift:266-274). */
+typedef struct { float origin[3], u[3], v[3], w[3], normal[3]; float d; size_t material_offset; } RtQuad;
+
+/* ---- material records: MetalRayTracer/Materials.h:16-93 -------------------- */
+
+enum RtMaterialKind {
+    rt_material_kind_lambertian_colored = 1,
+    rt_material_kind_lambertian_textured,
+    rt_material_kind_lambertian_perlin_noise,
+    rt_material_kind_metal_colored,
+    rt_material_kind_metal_textured,
+    rt_material_kind_metal_perlin_noise,
+    rt_material_kind_dielectric,
+    rt_material_kind_emissive_colored,
+    rt_material_kind_isotropic_colored,
+};
+
+/* Materials.h:30-36: the Metal resource id becomes the id rt_add_texture_rgb8 returned. */
+typedef struct { uint32_t texture_id; } RtImageTexture;
+
+/* Materials.h:38-45 */
+#define RT_PERLIN_TABLE_SIZE 256
+typedef struct {
+    float colors[2][3];
+    float frequency;
+    uint32_t turbulence;
+    float vectors[RT_PERLIN_TABLE_SIZE][3];
+    uint8_t permutations[3][RT_PERLIN_TABLE_SIZE];
+} RtPerlinNoiseTexture;
+
+/* Materials.h:47-93.  The first 4 bytes of every record are its kind. */
+typedef struct { uint32_t kind; float albedo[3]; } RtColoredLambertianMaterial;
+typedef struct { uint32_t kind; RtImageTexture albedo; } RtTexturedLambertianMaterial;
+typedef struct { uint32_t kind; RtPerlinNoiseTexture albedo; } RtPerlinNoiseLambertianMaterial;
+typedef struct { uint32_t kind; float albedo[3]; float fuzz; } RtColoredMetalMaterial;
+typedef struct { uint32_t kind; RtImageTexture albedo; float fuzz; } RtTexturedMetalMaterial;
+typedef struct { uint32_t kind; RtPerlinNoiseTexture albedo; float fuzz; } RtPerlinNoiseMetalMaterial;
+typedef struct { uint32_t kind; float refraction_index; } RtDielectricMaterial;
+typedef struct { uint32_t kind; float albedo[3]; } RtColoredEmissiveMaterial;
+typedef struct { uint32_t kind; float albedo[3]; } RtColoredIsotropicMaterial;
+
+/* ---- configuration: MetalRayTracer/Config.h:13-33 -------------------------- */
+
+enum RtBackgroundLighting { rt_background_lighting_none, rt_background_lighting_sky };
+
+/* Config.h:18-26 */
+typedef struct {
+    float vertical_FOV;
+    float look_from[3], look_at[3], up[3];
+    float defocus_angle;
+    float focus_distance;
+    uint32_t background;
+} RtCameraConfig;
+
+/* Config.h:28-33.  samples_per_pixel more samples are ADDED to the accumulator by one
+ * rt_render call.  pass_counter keeps the reference's meaning (number of the pass, 1
+ * based) and, because each pass here may hold many samples, first_sample gives the
+ * global index of the call's first sample: sample s of pixel (x, y) always uses the same
+ * random stream, whichever call, pipeline or GPU renders it. */
+typedef struct {
+    uint32_t samples_per_pixel;
+    uint32_t max_depth;
+    uint32_t pass_counter;
+    uint32_t first_sample;
+    uint64_t rng_seed;
+} RtRenderConfig;
+
+/* ---- results ----------------------------------------------------------------- */
+
+/* Closest accepted hit (Shaders.metal:171-203 + HitTesting.h:17-33). */
+typedef struct {
+    float t;
+    float point[3];
+    float normal[3];          /* flipped to oppose the ray */
+    float uv[2];
+    int32_t object;           /* index returned by rt_add_object, -1 = miss */
+    uint32_t material_offset; /* handle returned by rt_add_material */
+    int32_t front_face;       /* 1 = front, 0 = back */
+} RtHit;
+
+/* One boundary crossing of a shape along a ray (the hit enumerators of
+ * Impl/RenderableImpl.h: hasNext/isExit/t/point/normal/material_offset/
+ * texture_coordinates). */
+typedef struct {
+    float t;
+    float point[3];
+    float normal[3];          /* as enumerated: not flipped against the ray */
+    float uv[2];
+    uint32_t material_offset;
+    int32_t is_exit;
+    int32_t pad;
+} RtEvent;
+
+typedef struct {
+    uint32_t n_objects, n_nodes, bvh_depth;
+    uint32_t n_spheres, n_cylinders, n_cuboids, n_quads, n_csg, n_cdv;
+    uint32_t n_materials, n_textures, n_perlin;
+    uint64_t device_bytes;
+} RtSceneStats;
+
+enum RtCsgOp { RT_CSG_UNION = 0, RT_CSG_INTERSECTION = 1, RT_CSG_SUBTRACT = 2 };
+
+/* Which form of the render loop runs (both give the same estimator, sample for
+ * sample; they differ in where path state lives). */
+enum RtPipeline {
+    RT_PIPELINE_WAVEFRONT = 0,   /* ray-gen / extend / shade kernels over path queues in HBM */
+    RT_PIPELINE_FUSED = 1,       /* one persistent kernel, the stages as wave-wide phases, paths regenerated in place */
+};
+
+#define RT_CSG_MAX_LEAVES 8      /* leaf primitives under one CSG object */
+#define RT_MAX_EVENTS 16         /* boundary crossings rt_intervals can report per ray */
+
+typedef struct RtContext RtContext;
+typedef struct RtScene RtScene;
+
+/* ---- context ----------------------------------------------------------------- */
+
+/* Replaces MTLCreateSystemDefaultDevice + makeCommandQueue (ContentView.swift:122-128). */
+int rt_context_create(int device_ordinal, RtContext **out);
+void rt_context_destroy(RtContext *);
+const char *rt_last_error(void);
+int rt_abi_version(void);
+
+/* ---- scene description: replaces SceneBuffers.init (SceneBuffers.swift:15-72) -- */
+
+int rt_scene_create(RtContext *, RtScene **out);
+void rt_scene_destroy(RtScene *);
+
+/* MaterialEncoder.encode (Material.swift:46-56): appends one record (any of the nine
+ * structs above; size must match its kind) and returns its handle, to be stored in the
+ * *_material_offset fields.  Handles count 0, 1, 2 ... in call order. */
+int rt_add_material(RtScene *, const void *record, size_t size);
+/* TextureLoader.load (Texture.swift:20-41): 8-bit RGB, rows top to bottom; texture
+ * coordinate v = 0 is the bottom row as with the reference's bottom-left origin. */
+int rt_add_texture_rgb8(RtScene *, int width, int height, const uint8_t *rgb);
+
+/* Renderable.asImpl (Primitives.swift:39-42,133-145,186-193,266-274): returns a shape id. */
+int rt_shape_sphere(RtScene *, const RtSphere *);
+int rt_shape_cylinder(RtScene *, const RtCylinder *);
+int rt_shape_cuboid(RtScene *, const RtCuboid *);
+int rt_shape_quad(RtScene *, const RtQuad *);
+/* Subtract / Union / Intersection (CSG.swift:8-119; Impl/RenderableImpl.h:506-523):
+ * children are shape ids (primitives or other CSG shapes); for RT_CSG_SUBTRACT child 0
+ * is the left-hand side.  At most RT_CSG_MAX_LEAVES primitives in total. */
+int rt_shape_csg(RtScene *, int op, int n_children, const int *children);
+/* ConstantDensityVolume (ConstantDensityVolume.swift:8-33; RenderableImpl.h:717-725). */
+int rt_shape_cdv(RtScene *, int base_shape, float density);
+/* RenderableGrouper.add (SceneBuffers.swift:116-119): makes a shape a scene object. */
+int rt_add_object(RtScene *, int shape);
+/* Acceleration-structure build + upload (SceneBuffers.swift:42-71;
+ * BoundingVolumeNode.init, RayTracingKit/Hittable.swift:609-631). */
+int rt_scene_commit(RtScene *);
+int rt_scene_stats(const RtScene *, RtSceneStats *out);
+
+/* ---- queries (parity surface) ------------------------------------------------ */
+
+/* Closest hit of n rays (rays_dev: n x 6 floats, origin then direction) with
+ * tmin <= t <= tmax.  volume_key is the 64-bit word that keys the free-flight draws of
+ * constant-density volumes (the renderer passes the path generator's state). */
+int rt_first_hit(RtScene *, const float *rays_dev, int n, float tmin, float tmax,
+                 uint64_t volume_key, RtHit *out_dev, void *stream);
+
+/* Ordered boundary crossings of one shape along n rays: events_dev holds
+ * n x RT_MAX_EVENTS records, counts_dev n counts.  scripted_u_dev (may be NULL) replaces
+ * the volume's random numbers by the given values, cycled in order, which is the
+ * reference's test generator (Impl/RNG.h:15-27). */
+int rt_intervals(RtScene *, int shape, const float *rays_dev, int n,
+                 const float *scripted_u_dev, int n_scripted, uint64_t volume_key,
+                 RtEvent *events_dev, int32_t *counts_dev, void *stream);
+
+/* The ray-generation stage alone (Shaders.metal:30-67): rays of samples
+ * first_sample .. first_sample+samples_per_pixel-1 of the pixels of the window
+ * [x0,x0+w) x [y0,y0+h), pixel-major then sample; out n x 6 floats. */
+int rt_camera_rays(RtContext *, const RtCameraConfig *, const RtRenderConfig *,
+                   int width, int height, int x0, int y0, int w, int h,
+                   float *rays_out_dev, void *stream);
+
+/* ---- render: replaces Renderer.draw (ContentView.swift:182-224) --------------- */
+
+/* Device scratch the render loop needs for a width x height image. */
+size_t rt_render_workspace_size(int pipeline, int width, int height);
+
+/* Adds config->samples_per_pixel samples per pixel to accum_dev: width*height*3 floats,
+ * the per-pixel RGB radiance SUMS (row-major, interleaved RGB).  The caller keeps the
+ * sample count (the reference keeps passCounter on the host too, ContentView.swift:187).
+ * workspace_dev must hold rt_render_workspace_size bytes. */
+int rt_render(RtScene *, const RtCameraConfig *, const RtRenderConfig *, int pipeline,
+              int width, int height, float *accum_dev,
+              void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* Camera.swift:92 / Vector3D.swift:181-211: mean -> min(sqrt(x), 1) ->
+ * floor(255.999.. * x), written as RGBX8 (width*height*4 bytes). */
+int rt_resolve_rgb8(RtContext *, const float *accum_dev, int width, int height,
+                    uint8_t *rgbx_out_dev, void *stream);
+
+/* Timing of the render loop's dominant kernel on its own stream (HIP events around
+ * every launch since the last reset): total milliseconds and launch count. */
+int rt_kernel_time(RtScene *, int reset, double *total_ms, uint64_t *launches, const char **kernel_name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

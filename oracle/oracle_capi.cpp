@@ -1,0 +1,257 @@
+// oracle_capi.cpp - extern "C" surface of the CPU oracle (test infrastructure only;
+// see oracle_api.h for who may load it).
+#include "oracle.hpp"
+
+#include <atomic>
+#include <thread>
+
+using namespace orc;
+
+struct OrcScene { Scene s; };
+
+static thread_local std::string g_err;
+static int fail(const std::string &m) { g_err = m; return -1; }
+
+// All orc_* functions get C linkage from their declarations in oracle_api.h.
+
+const char *orc_last_error(void) { return g_err.c_str(); }
+
+OrcScene *orc_scene_create(void) { return new OrcScene(); }
+void orc_scene_destroy(OrcScene *s) { delete s; }
+
+int orc_add_material(OrcScene *s, const OrcMaterial *m) {
+    if (m->kind < 1 || m->kind > 9) return fail("material kind out of range");
+    s->s.materials.push_back(*m);
+    return (int)s->s.materials.size() - 1;
+}
+
+int orc_add_texture_rgb8(OrcScene *s, int w, int h, const uint8_t *rgb) {
+    if (w <= 0 || h <= 0) return fail("empty texture");
+    Image im;
+    im.w = w; im.h = h;
+    im.rgb.assign(rgb, rgb + (size_t)3 * w * h);
+    s->s.images.push_back(std::move(im));
+    return (int)s->s.images.size() - 1;
+}
+
+int orc_add_perlin(OrcScene *s, const OrcPerlin *p) {
+    s->s.perlins.push_back(*p);
+    return (int)s->s.perlins.size() - 1;
+}
+
+static void set_xf(Shape &sh, const OrcTransform &t) {
+    for (int i = 0; i < 9; i++) sh.rot[i] = t.rotation[i];
+    for (int i = 0; i < 3; i++) sh.trans[i] = t.translation[i];
+}
+static int push(OrcScene *s, Shape &&sh) {
+    s->s.committed = false;
+    s->s.shapes.push_back(std::move(sh));
+    return (int)s->s.shapes.size() - 1;
+}
+
+int orc_shape_sphere(OrcScene *s, const OrcSphere *p) {
+    Shape sh; sh.kind = SPHERE; set_xf(sh, p->transform); sh.radius = p->radius; sh.mat[0] = p->material_offset;
+    return push(s, std::move(sh));
+}
+int orc_shape_cylinder(OrcScene *s, const OrcCylinder *p) {
+    Shape sh; sh.kind = CYLINDER; set_xf(sh, p->transform); sh.radius = p->radius; sh.height = p->height;
+    sh.mat[0] = p->bottom_material_offset; sh.mat[1] = p->top_material_offset; sh.mat[2] = p->side_material_offset;
+    return push(s, std::move(sh));
+}
+int orc_shape_cuboid(OrcScene *s, const OrcCuboid *p) {
+    Shape sh; sh.kind = CUBOID; set_xf(sh, p->transform);
+    for (int i = 0; i < 3; i++) sh.size[i] = p->size[i];
+    for (int i = 0; i < 6; i++) sh.mat[i] = p->material_offset[i];
+    return push(s, std::move(sh));
+}
+int orc_shape_quad(OrcScene *s, const OrcQuad *p) {
+    Shape sh; sh.kind = QUAD;
+    for (int i = 0; i < 3; i++) {
+        sh.q_origin[i] = p->origin[i]; sh.q_u[i] = p->u[i]; sh.q_v[i] = p->v[i];
+        sh.q_w[i] = p->w[i]; sh.q_normal[i] = p->normal[i];
+    }
+    sh.q_d = p->d; sh.mat[0] = p->material_offset;
+    return push(s, std::move(sh));
+}
+int orc_shape_csg(OrcScene *s, int op, int n, const int *children) {
+    if (n < 1) return fail("composition needs children");
+    Shape sh; sh.kind = COMPOSITION;
+    for (int i = 0; i < n; i++) {
+        if (children[i] < 0 || children[i] >= (int)s->s.shapes.size()) return fail("bad child shape id");
+        sh.children.push_back(children[i]);
+    }
+    // RenderableImpl.h:515-522
+    sh.subtract = op == ORC_OP_SUBTRACT;
+    sh.min_count = op == ORC_OP_INTERSECTION ? n : 1;
+    return push(s, std::move(sh));
+}
+int orc_shape_cdv(OrcScene *s, int base, float density) {
+    if (base < 0 || base >= (int)s->s.shapes.size()) return fail("bad base shape id");
+    Shape sh; sh.kind = CDV; sh.base = base; sh.density = density;
+    return push(s, std::move(sh));
+}
+int orc_add_object(OrcScene *s, int shape) {
+    if (shape < 0 || shape >= (int)s->s.shapes.size()) return fail("bad shape id");
+    s->s.committed = false;
+    s->s.objects.push_back(shape);
+    return (int)s->s.objects.size() - 1;
+}
+int orc_commit(OrcScene *s) { commit(s->s); return 0; }
+
+template <class R>
+static int enumerate_t(const Scene &sc, int shape, const double o[3], const double d[3],
+                       const float *script, int n_script, OrcEvent *out, int max_out) {
+    Rng scripted;
+    scripted.script = script; scripted.n_script = n_script;
+    TraceCtx<R> ctx{&sc, nullptr, script ? &scripted : nullptr, 0};
+    Ray<R> ray{V3<R>(R(o[0]), R(o[1]), R(o[2])), V3<R>(R(d[0]), R(d[1]), R(d[2]))};
+    auto e = make_enum<R>(ctx, shape, ray, 0);
+    int n = 0;
+    for (; e->hasNext() && n < max_out; e->move(), n++) {
+        OrcEvent &ev = out[n];
+        ev.t = (double)e->t();
+        ev.is_exit = e->isExit();
+        ev.material_offset = 0;
+        ev.pad = 0;
+        for (int i = 0; i < 3; i++) ev.point[i] = ev.normal[i] = 0;
+        ev.uv[0] = ev.uv[1] = 0;
+        if (std::isfinite(ev.t)) {
+            V3<R> p = e->point(), nn = e->normal();
+            ev.point[0] = p.x; ev.point[1] = p.y; ev.point[2] = p.z;
+            ev.normal[0] = nn.x; ev.normal[1] = nn.y; ev.normal[2] = nn.z;
+            R u, v;
+            e->texture_coordinates(u, v);
+            ev.uv[0] = u; ev.uv[1] = v;
+            ev.material_offset = e->material_offset();
+        }
+    }
+    return n;
+}
+
+int orc_enumerate(const OrcScene *s, int shape, int precision, const double origin[3], const double direction[3],
+                  const float *scripted_rng, int n_scripted, OrcEvent *out, int max_out) {
+    if (shape < 0 || shape >= (int)s->s.shapes.size()) return fail("bad shape id");
+    if (precision == ORC_F32) return enumerate_t<float>(s->s, shape, origin, direction, scripted_rng, n_scripted, out, max_out);
+    return enumerate_t<double>(s->s, shape, origin, direction, scripted_rng, n_scripted, out, max_out);
+}
+
+template <class R>
+static void first_hit_t(const Scene &sc, int n, const double *rays, double tmin, double tmax, uint64_t cdv_state, OrcHit *out) {
+    for (int i = 0; i < n; i++) {
+        const double *r = rays + 6 * (size_t)i;
+        Ray<R> ray{V3<R>(R(r[0]), R(r[1]), R(r[2])), V3<R>(R(r[3]), R(r[4]), R(r[5]))};
+        TraceCtx<R> ctx{&sc, nullptr, nullptr, cdv_state};
+        HitInfo<R> h;
+        OrcHit &o = out[i];
+        std::memset(&o, 0, sizeof(o));
+        o.object = -1;
+        if (scene_hit<R>(ctx, ray, R(tmin), R(tmax), h)) {
+            o.t = h.t;
+            o.point[0] = h.point.x; o.point[1] = h.point.y; o.point[2] = h.point.z;
+            o.normal[0] = h.normal.x; o.normal[1] = h.normal.y; o.normal[2] = h.normal.z;
+            o.uv[0] = h.u; o.uv[1] = h.v;
+            o.material_offset = h.material_offset;
+            o.object = h.object;
+            o.front_face = h.front ? 1 : 0;
+        }
+    }
+}
+
+int orc_first_hit(const OrcScene *s, int precision, int n, const double *rays, double tmin, double tmax,
+                  uint64_t cdv_state, OrcHit *out) {
+    if (!s->s.committed) return fail("scene not committed");
+    if (precision == ORC_F32) first_hit_t<float>(s->s, n, rays, tmin, tmax, cdv_state, out);
+    else first_hit_t<double>(s->s, n, rays, tmin, tmax, cdv_state, out);
+    return 0;
+}
+
+template <class R>
+static void camera_rays_t(const OrcCameraConfig *cc, int width, int height, const OrcRenderConfig *rc,
+                          int x0, int y0, int w, int h, double *out) {
+    Camera<R> cam(width, height, *cc);
+    size_t k = 0;
+    for (int y = y0; y < y0 + h; y++)
+        for (int x = x0; x < x0 + w; x++)
+            for (uint32_t s = 0; s < rc->samples_per_pixel; s++) {
+                Rng rng;
+                rng.pcg = sample_stream(rc->rng_seed, rc->first_sample + s, (uint32_t)x, (uint32_t)y);
+                Ray<R> r = cam.get_ray((uint32_t)x, (uint32_t)y, rng);
+                out[k++] = r.origin.x; out[k++] = r.origin.y; out[k++] = r.origin.z;
+                out[k++] = r.direction.x; out[k++] = r.direction.y; out[k++] = r.direction.z;
+            }
+}
+
+int orc_camera_rays(const OrcCameraConfig *cc, int precision, int width, int height, const OrcRenderConfig *rc,
+                    int x0, int y0, int w, int h, double *out) {
+    if (precision == ORC_F32) camera_rays_t<float>(cc, width, height, rc, x0, y0, w, h, out);
+    else camera_rays_t<double>(cc, width, height, rc, x0, y0, w, h, out);
+    return 0;
+}
+
+// Row-parallel like Camera.swift:62-80 (one task per row); workers pull rows from a
+// shared counter.  Unlike Camera.swift:82-83 the generator is per (pixel, sample), so the
+// image does not depend on the number of workers.
+template <class R>
+static void render_t(const Scene &sc, const OrcCameraConfig *cc, const OrcRenderConfig *rc, int width, int height,
+                     int x0, int y0, int w, int h, int threads, double *out_sum, OrcCounters *counters) {
+    Camera<R> cam(width, height, *cc);
+    std::atomic<int> next_row(0);
+    std::vector<Counters> per_thread((size_t)threads);
+    auto worker = [&](int tid) {
+        Counters *cnt = counters ? &per_thread[(size_t)tid] : nullptr;
+        while (true) {
+            int row = next_row.fetch_add(1);
+            if (row >= h) break;
+            int y = y0 + row;
+            for (int col = 0; col < w; col++) {
+                int x = x0 + col;
+                V3<R> color;    // accumulates in R like Camera.swift:86-91
+                for (uint32_t s = 0; s < rc->samples_per_pixel; s++) {
+                    Rng rng;
+                    rng.pcg = sample_stream(rc->rng_seed, rc->first_sample + s, (uint32_t)x, (uint32_t)y);
+                    Ray<R> ray = cam.get_ray((uint32_t)x, (uint32_t)y, rng);
+                    color = color + ray_color<R>(sc, cc->background, ray, (int)rc->max_depth, rng, cnt);
+                    if (cnt) cnt->samples++;
+                }
+                double *o = out_sum + 3 * ((size_t)row * w + col);
+                o[0] = color.x; o[1] = color.y; o[2] = color.z;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto &t : pool) t.join();
+    if (counters) {
+        Counters total;
+        for (auto &c : per_thread) total.add(c);
+        counters->samples = total.samples; counters->rays = total.rays; counters->hits = total.hits;
+        counters->box_tests = total.box_tests;
+        for (int i = 0; i < 4; i++) counters->prim_tests[i] = total.prim_tests[i];
+        counters->csg_events = total.csg_events; counters->cdv_intervals = total.cdv_intervals;
+        for (int i = 0; i < 10; i++) counters->shades[i] = total.shades[i];
+    }
+}
+
+int orc_render(const OrcScene *s, const OrcCameraConfig *cc, const OrcRenderConfig *rc, int precision,
+               int width, int height, int x0, int y0, int w, int h, int threads, double *out_sum, OrcCounters *counters) {
+    if (!s->s.committed) return fail("scene not committed");
+    if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (precision == ORC_F32) render_t<float>(s->s, cc, rc, width, height, x0, y0, w, h, threads, out_sum, counters);
+    else render_t<double>(s->s, cc, rc, width, height, x0, y0, w, h, threads, out_sum, counters);
+    return threads;
+}
+
+void orc_pcg32(uint64_t initstate, uint64_t initseq, int n, uint32_t *out) {
+    Pcg32 g(initstate, initseq);
+    for (int i = 0; i < n; i++) out[i] = g.next_u32();
+}
+void orc_wyrand(uint64_t seed, int n, uint64_t *out) {
+    for (int i = 0; i < n; i++) out[i] = wyrand_at(seed, (uint64_t)i);
+}
+void orc_sample_stream(uint64_t rng_seed, uint32_t sample, uint32_t x, uint32_t y, uint64_t out_state_inc[2]) {
+    Pcg32 g = sample_stream(rng_seed, sample, x, y);
+    out_state_inc[0] = g.state;
+    out_state_inc[1] = g.inc;
+}
+

@@ -1,0 +1,229 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) for the tests.
+
+The oracle is test infrastructure: this file lives under tests/ and nothing in the
+raytracer_amd package imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raytracer_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+ORC_F32, ORC_F64 = 0, 1
+
+
+class OrcMaterial(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("albedo", C.c_float * 3), ("fuzz", C.c_float),
+                ("refraction_index", C.c_float), ("texture", C.c_uint32)]
+
+
+class OrcEvent(C.Structure):
+    _fields_ = [("t", C.c_double), ("point", C.c_double * 3), ("normal", C.c_double * 3), ("uv", C.c_double * 2),
+                ("material_offset", C.c_uint64), ("is_exit", C.c_int32), ("pad", C.c_int32)]
+
+
+class OrcHit(C.Structure):
+    _fields_ = [("t", C.c_double), ("point", C.c_double * 3), ("normal", C.c_double * 3), ("uv", C.c_double * 2),
+                ("material_offset", C.c_uint64), ("object", C.c_int32), ("front_face", C.c_int32)]
+
+
+class OrcCounters(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("hits", C.c_uint64), ("box_tests", C.c_uint64),
+                ("prim_tests", C.c_uint64 * 4), ("csg_events", C.c_uint64), ("cdv_intervals", C.c_uint64),
+                ("shades", C.c_uint64 * 10)]
+
+    def as_dict(self):
+        return {"samples": self.samples, "rays": self.rays, "hits": self.hits, "box_tests": self.box_tests,
+                "prim_tests": list(self.prim_tests), "csg_events": self.csg_events,
+                "cdv_intervals": self.cdv_intervals, "shades": list(self.shades)}
+
+
+class OrcRenderConfig(C.Structure):
+    _fields_ = [("samples_per_pixel", C.c_uint32), ("max_depth", C.c_uint32), ("first_sample", C.c_uint32),
+                ("rng_seed", C.c_uint64)]
+
+
+HIT_DTYPE = np.dtype([("t", "f8"), ("point", "f8", 3), ("normal", "f8", 3), ("uv", "f8", 2),
+                      ("material_offset", "u8"), ("object", "i4"), ("front_face", "i4")])
+assert HIT_DTYPE.itemsize == C.sizeof(OrcHit)
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.orc_scene_create.restype = C.c_void_p
+        L.orc_last_error.restype = C.c_char_p
+        for name in ("orc_scene_destroy", "orc_add_material", "orc_add_texture_rgb8", "orc_add_perlin",
+                     "orc_shape_sphere", "orc_shape_cylinder", "orc_shape_cuboid", "orc_shape_quad",
+                     "orc_shape_csg", "orc_shape_cdv", "orc_add_object", "orc_commit", "orc_enumerate",
+                     "orc_first_hit", "orc_render"):
+            getattr(L, name).argtypes = None
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+    return rc
+
+
+class OracleScene:
+    """Sink for raytracer_amd.scene.SceneEncoder that feeds the oracle.  The geometry
+    records are passed as they are (the oracle's input structs have the same layout as
+    include/raytracer_amd.h); material records are flattened to the oracle's one struct."""
+
+    def __init__(self):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.orc_scene_create())
+        self.committed = False
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_scene_destroy(self.h)
+            self.h = None
+
+    # ---- sink protocol
+    def add_material(self, rec):
+        m = OrcMaterial()
+        m.kind = rec.kind
+        k = rec.kind
+        if k in (abi.material_kind_lambertian_colored, abi.material_kind_metal_colored,
+                 abi.material_kind_emissive_colored, abi.material_kind_isotropic_colored):
+            m.albedo = rec.albedo
+        if k in (abi.material_kind_lambertian_textured, abi.material_kind_metal_textured):
+            m.texture = rec.albedo.texture_id
+        if k in (abi.material_kind_lambertian_perlin_noise, abi.material_kind_metal_perlin_noise):
+            m.texture = _check(self.L.orc_add_perlin(self.h, C.byref(rec.albedo)))
+        if k in (abi.material_kind_metal_colored, abi.material_kind_metal_textured, abi.material_kind_metal_perlin_noise):
+            m.fuzz = rec.fuzz
+        if k == abi.material_kind_dielectric:
+            m.refraction_index = rec.refraction_index
+        return _check(self.L.orc_add_material(self.h, C.byref(m)))
+
+    def add_dummy_materials(self, n):
+        for _ in range(n):
+            self.add_material(abi.RtColoredLambertianMaterial(abi.material_kind_lambertian_colored, abi.F3(.5, .5, .5)))
+
+    def add_texture_rgb8(self, w, h, pixels):
+        buf = np.ascontiguousarray(pixels, dtype=np.uint8)
+        return _check(self.L.orc_add_texture_rgb8(self.h, C.c_int(w), C.c_int(h), buf.ctypes.data_as(C.c_void_p)))
+
+    def shape_sphere(self, rec):
+        return _check(self.L.orc_shape_sphere(self.h, C.byref(rec)))
+
+    def shape_cylinder(self, rec):
+        return _check(self.L.orc_shape_cylinder(self.h, C.byref(rec)))
+
+    def shape_cuboid(self, rec):
+        return _check(self.L.orc_shape_cuboid(self.h, C.byref(rec)))
+
+    def shape_quad(self, rec):
+        return _check(self.L.orc_shape_quad(self.h, C.byref(rec)))
+
+    def shape_csg(self, op, ids):
+        arr = (C.c_int * len(ids))(*ids)
+        return _check(self.L.orc_shape_csg(self.h, C.c_int(op), C.c_int(len(ids)), arr))
+
+    def shape_cdv(self, base, density):
+        return _check(self.L.orc_shape_cdv(self.h, C.c_int(base), C.c_float(density)))
+
+    def add_object(self, shape):
+        return _check(self.L.orc_add_object(self.h, C.c_int(shape)))
+
+    def add_spheres_bulk(self, centers, radii, mat_ids):
+        for c, r, m in zip(centers, radii, mat_ids):
+            rec = abi.RtSphere()
+            rec.transform.rotation = (C.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
+            rec.transform.translation = abi.F3(*[float(v) for v in c])
+            rec.radius = float(r)
+            rec.material_offset = int(m)
+            self.add_object(self.shape_sphere(rec))
+
+    def commit(self):
+        _check(self.L.orc_commit(self.h))
+        self.committed = True
+
+    # ---- queries
+    def enumerate(self, shape, origin, direction, precision=ORC_F32, scripted=None, max_out=32):
+        o = (C.c_double * 3)(*[float(v) for v in origin])
+        d = (C.c_double * 3)(*[float(v) for v in direction])
+        ev = (OrcEvent * max_out)()
+        if scripted:
+            s = (C.c_float * len(scripted))(*scripted)
+            n = self.L.orc_enumerate(self.h, C.c_int(shape), C.c_int(precision), o, d, s, C.c_int(len(scripted)), ev,
+                                     C.c_int(max_out))
+        else:
+            n = self.L.orc_enumerate(self.h, C.c_int(shape), C.c_int(precision), o, d, None, C.c_int(0), ev,
+                                     C.c_int(max_out))
+        _check(n)
+        return [ev[i] for i in range(n)]
+
+    def first_hit(self, rays, tmin=1e-3, tmax=float("inf"), precision=ORC_F64, volume_key=0):
+        if not self.committed:
+            self.commit()
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        out = np.zeros(len(rays), dtype=HIT_DTYPE)
+        _check(self.L.orc_first_hit(self.h, C.c_int(precision), C.c_int(len(rays)), rays.ctypes.data_as(C.c_void_p),
+                                    C.c_double(tmin), C.c_double(tmax), C.c_uint64(volume_key),
+                                    out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def render(self, camera, config, width, height, window=None, precision=ORC_F64, threads=0, counters=False):
+        """Returns (sum image [h, w, 3] float64, threads used, counters dict or None)."""
+        if not self.committed:
+            self.commit()
+        x0, y0, w, h = window if window else (0, 0, width, height)
+        cc = camera.impl
+        rc = OrcRenderConfig(config.samples_per_pixel, config.max_depth, config.first_sample, config.rng_seed)
+        out = np.zeros((h, w, 3), dtype=np.float64)
+        cnt = OrcCounters()
+        used = _check(self.L.orc_render(self.h, C.byref(cc), C.byref(rc), C.c_int(precision), C.c_int(width),
+                                        C.c_int(height), C.c_int(x0), C.c_int(y0), C.c_int(w), C.c_int(h),
+                                        C.c_int(threads), out.ctypes.data_as(C.c_void_p),
+                                        C.byref(cnt) if counters else None))
+        return out, used, (cnt.as_dict() if counters else None)
+
+
+def camera_rays(camera, config, width, height, window=None, precision=ORC_F32):
+    x0, y0, w, h = window if window else (0, 0, width, height)
+    cc = camera.impl
+    rc = OrcRenderConfig(config.samples_per_pixel, config.max_depth, config.first_sample, config.rng_seed)
+    out = np.zeros((w * h * config.samples_per_pixel, 6), dtype=np.float64)
+    lib().orc_camera_rays(C.byref(cc), C.c_int(precision), C.c_int(width), C.c_int(height), C.byref(rc),
+                          C.c_int(x0), C.c_int(y0), C.c_int(w), C.c_int(h), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def pcg32(initstate, initseq, n):
+    out = (C.c_uint32 * n)()
+    lib().orc_pcg32(C.c_uint64(initstate), C.c_uint64(initseq), C.c_int(n), out)
+    return list(out)
+
+
+def wyrand(seed, n):
+    out = (C.c_uint64 * n)()
+    lib().orc_wyrand(C.c_uint64(seed), C.c_int(n), out)
+    return list(out)
+
+
+def oracle_scene_from(scene, dedup=True):
+    sink = OracleScene()
+    scene.encode(sink, dedup=dedup)
+    sink.commit()
+    return sink
