@@ -21,7 +21,7 @@ def test_enumerator_known_answers(case, precision):
     # compiled without fused multiply-add, so the cancelling discriminant of the rotated
     # cylinder case (b^2 - a*c with both terms near 14) lands 2.7e-6 from the literal the
     # reference's FMA-contracting compiler reaches (and the tube normal doubles that, being
-    divided by the radius 0.5); the float build is held to 2^-17 instead.
+    # divided by the radius 0.5); the float build is held to 2^-17 instead.
     tol = FIX["tolerance"] * (8 if precision == ob.ORC_F32 else 1)
     if case.get("first_only"):
         assert len(events) >= 1
