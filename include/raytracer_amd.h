@@ -210,6 +210,12 @@ int rt_shape_csg(RtScene *, int op, int n_children, const int *children);
 int rt_shape_cdv(RtScene *, int base_shape, float density);
 /* RenderableGrouper.add (SceneBuffers.swift:116-119): makes a shape a scene object. */
 int rt_add_object(RtScene *, int shape);
+/* Bulk form of rt_shape_sphere + rt_add_object for n plain spheres (identity rotation):
+ * center_radius holds n x 4 floats (cx, cy, cz, r).  No counterpart in the reference,
+ * whose scenes hold a handful of objects; it exists so that a million-sphere scene does
+ * not cost a million calls.  Must come after every rt_add_object; returns the object
+ * index of the first sphere. */
+int rt_add_sphere_objects(RtScene *, int n, const float *center_radius, const uint32_t *material_offsets);
 /* Acceleration-structure build + upload (SceneBuffers.swift:42-71;
  * BoundingVolumeNode.init, RayTracingKit/Hittable.swift:609-631). */
 int rt_scene_commit(RtScene *);
@@ -252,8 +258,9 @@ int rt_render(RtScene *, const RtCameraConfig *, const RtRenderConfig *, int pip
               void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* Camera.swift:92 / Vector3D.swift:181-211: mean -> min(sqrt(x), 1) ->
- * floor(255.999.. * x), written as RGBX8 (width*height*4 bytes). */
-int rt_resolve_rgb8(RtContext *, const float *accum_dev, int width, int height,
+ * floor(255.999.. * x), written as RGBX8 (width*height*4 bytes); n_samples is the number
+ * of samples per pixel the sums hold. */
+int rt_resolve_rgb8(RtContext *, const float *accum_dev, uint32_t n_samples, int width, int height,
                     uint8_t *rgbx_out_dev, void *stream);
 
 /* Timing of the render loop's dominant kernel on its own stream (HIP events around

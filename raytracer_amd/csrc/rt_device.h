@@ -1,0 +1,802 @@
+// rt_device.h - device-side building blocks of the path tracer (gfx950).
+//
+// Stages, in the order a path goes through them:
+//   raygen  camera ray of one (pixel, sample)            Shaders.metal:20-68
+//   extend  BVH traversal + closed-form primitive tests   RenderableImpl.h, Hittable.swift:637-645
+//   shade   hit completion + material scatter             MaterialsImpl.h:147-215
+// The kernels in rt_kernels.hip compose them either as separate launches over path
+// queues or as wave-wide phases of one persistent kernel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_shared.h"
+
+#define RT_DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------ small vector type
+struct f3 { float x, y, z; };
+RT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_DEV f3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+RT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+RT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_DEV f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_DEV float dot(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+RT_DEV f3 cross(f3 a, f3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+RT_DEV f3 madd(f3 a, float s, f3 b) { return mk3(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z)); }  // a*s + b
+RT_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+RT_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+RT_DEV f3 normalize3(f3 a) { return a * __builtin_amdgcn_rsqf(dot(a, a)); }
+RT_DEV bool finite(float x) { return fabsf(x) < __builtin_huge_valf(); }
+
+#define RT_INF __builtin_huge_valf()
+#define RT_PI 3.14159265358979323846f
+
+// ------------------------------------------------------------------ random numbers
+// PCG32, Impl/RNG.h:31-52.
+struct Pcg { uint64_t state, inc; };
+
+RT_DEV uint32_t pcg_next(Pcg &g) {
+    uint64_t old = g.state;
+    g.state = old * 6364136223846793005ULL + g.inc;
+    uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((0u - rot) & 31u));
+}
+
+RT_DEV Pcg pcg_seed(uint64_t initstate, uint64_t initseq) {   // RNG.h:37-44
+    Pcg g;
+    g.state = 0u;
+    g.inc = (initseq << 1u) | 1u;
+    pcg_next(g);
+    g.state += initstate;
+    pcg_next(g);
+    return g;
+}
+
+// Uniform in [0,1): the top 24 bits.  (RNG.h:54-56 scales all 32 bits, which can round to
+// 1.0f and then feeds log(0) to the volume sampler.)
+RT_DEV float rnd(Pcg &g) { return (float)(pcg_next(g) >> 8) * (1.0f / 16777216.0f); }
+
+// WyRand output number k of `seed` (RayTracingKit/PRNG.swift:17-21): the generator's state
+// after k+1 steps is seed + (k+1)*C, so every output is addressable by its index.
+RT_DEV uint64_t wyrand_at(uint64_t seed, uint64_t k) {
+    uint64_t s = seed + (k + 1) * 0xa0761d6478bd642fULL;
+    uint64_t t = s ^ 0xe7037ed1a0b428dbULL;
+    return __umul64hi(s, t) ^ (s * t);
+}
+
+// Generator of one (pixel, sample): per-sample seed = WyRand output `sample` of rng_seed
+// (the reference draws a new 64-bit seed for every one-sample pass,
+// ContentView.swift:201-202), pixel offsets as Shaders.metal:141-143.
+RT_DEV Pcg sample_stream(uint64_t rng_seed, uint32_t sample, uint32_t x, uint32_t y) {
+    uint64_t pass = wyrand_at(rng_seed, sample);
+    uint32_t lo = (uint32_t)pass, hi = (uint32_t)(pass >> 32);
+    return pcg_seed((uint64_t)(uint32_t)(x * 5569u + lo), (uint64_t)(uint32_t)(y * 2707u + hi));
+}
+
+#define RT_MIN_LEN_SQ 1e-24f   // RNG.h:13
+
+// RNG.h:59-68: rejection from the square, normalised onto the circle.
+RT_DEV void random_unit_vector_2d(Pcg &g, float &ox, float &oy) {
+    while (true) {
+        float x = rnd(g) * 2.0f - 1.0f;
+        float y = rnd(g) * 2.0f - 1.0f;
+        float len_sq = x * x + y * y;
+        if (RT_MIN_LEN_SQ < len_sq && len_sq <= 1.0f) {
+            float inv = __builtin_amdgcn_rsqf(len_sq);
+            ox = x * inv;
+            oy = y * inv;
+            return;
+        }
+    }
+}
+
+// RayTracingKit/Vector3D.swift:113-127 (RNG.h:70-80 forgets z*z in the length).
+RT_DEV f3 random_unit_vector_3d(Pcg &g) {
+    while (true) {
+        float x = rnd(g) * 2.0f - 1.0f;
+        float y = rnd(g) * 2.0f - 1.0f;
+        float z = rnd(g) * 2.0f - 1.0f;
+        float len_sq = fmaf(x, x, fmaf(y, y, z * z));
+        if (RT_MIN_LEN_SQ < len_sq && len_sq <= 1.0f) {
+            float inv = __builtin_amdgcn_rsqf(len_sq);
+            return mk3(x * inv, y * inv, z * inv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ ray generation
+// Shaders.metal:50-67 with the draw order of Camera.swift:97-100 (origin, offset x,
+// offset y) and no draw when there is no defocus (Camera.swift:108).
+RT_DEV void camera_ray(const RtDevCamera &c, uint32_t gx, uint32_t gy, Pcg &g, f3 &origin, f3 &dir) {
+    origin = ld3(c.center);
+    if (c.defocus) {
+        float px, py;
+        random_unit_vector_2d(g, px, py);
+        origin = madd(ld3(c.defocus_u), px, madd(ld3(c.defocus_v), py, origin));
+    }
+    float off_x = rnd(g);
+    float off_y = rnd(g);
+    float sx = ((float)gx + off_x) * c.inv_w - 0.5f;
+    float sy = ((float)gy + off_y) * c.inv_h - 0.5f;
+    f3 sample = madd(ld3(c.viewport_u), sx, madd(ld3(c.viewport_v), sy, ld3(c.viewport_center)));
+    dir = normalize3(sample - origin);
+}
+
+// Shaders.metal:76-86 (its a = 0.5*y + 1.0 kept as is).
+RT_DEV f3 background_color(uint32_t mode, f3 dir) {
+    if (mode == 0) return mk3(0, 0, 0);
+    float a = fmaf(0.5f, dir.y, 1.0f);
+    float w = 1.0f - a;
+    return mk3(fmaf(a, 0.5f, w), fmaf(a, 0.7f, w), fmaf(a, 1.0f, w));
+}
+
+// ------------------------------------------------------------------ primitive intervals
+// Every primitive is a convex volume (the quad a half space): along a ray it is one
+// interval [t0, t1].  tag0/tag1 say which surface the ends lie on (cylinder: 0 bottom cap,
+// 1 top cap, 2 tube; cuboid: face index left,right,bottom,top,back,front).
+struct Span { float t0, t1; uint32_t tag0, tag1; };
+RT_DEV Span empty_span() { Span s; s.t0 = RT_INF; s.t1 = -RT_INF; s.tag0 = s.tag1 = 0; return s; }
+RT_DEV bool span_valid(const Span &s) { return s.t0 <= s.t1; }
+
+struct XPrim { f3 c0, c1, c2, t; float p0, p1, p2, p3; };
+RT_DEV XPrim load_xprim(const RtDevScene &s, uint32_t idx) {
+    const float4 *q = (const float4 *)s.xprims + 4u * idx;
+    float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    XPrim x;
+    x.c0 = mk3(a.x, a.y, a.z);
+    x.c1 = mk3(a.w, b.x, b.y);
+    x.c2 = mk3(b.z, b.w, c.x);
+    x.t = mk3(c.y, c.z, c.w);
+    x.p0 = d.x; x.p1 = d.y; x.p2 = d.z; x.p3 = d.w;
+    return x;
+}
+RT_DEV f3 rot_t(const XPrim &x, f3 v) { return mk3(dot(x.c0, v), dot(x.c1, v), dot(x.c2, v)); }     // transpose(R) * v
+RT_DEV f3 rot(const XPrim &x, f3 v) { return madd(x.c0, v.x, madd(x.c1, v.y, x.c2 * v.z)); }          // R * v
+
+// Impl/RenderableImpl.h:30-56.  The discriminant is taken as a*(r^2 - |oc - (b/a) d|^2):
+// the same number as b^2 - a*c without subtracting two large squares.
+RT_DEV Span sphere_span(const RtDevScene &s, uint32_t idx, f3 o, f3 d) {
+    float4 g = ((const float4 *)s.spheres)[idx];
+    f3 oc = o - mk3(g.x, g.y, g.z);
+    float a = dot(d, d);
+    float b = dot(d, oc);
+    float inv_a = rcp(a);
+    float ba = b * inv_a;
+    f3 l = madd(d, -ba, oc);
+    float h = fmaf(g.w, g.w, -dot(l, l));
+    Span sp = empty_span();
+    if (h >= 0.0f) {
+        float root = fsqrt(h * a);
+        sp.t0 = (-b - root) * inv_a;
+        sp.t1 = (-b + root) * inv_a;
+    }
+    return sp;
+}
+
+// One slab of a box/cylinder in the local frame: RenderableImpl.h:102-139 and :269-308.
+RT_DEV void slab(float size, float origin, float direction, float &tin, float &tout, bool &in_is_low) {
+    float inv = rcp(direction);
+    float tb = -origin * inv;
+    float tt = (size - origin) * inv;
+    if (finite(tb) && finite(tt)) {
+        in_is_low = !(tb > tt);
+        tin = fminf(tb, tt);
+        tout = fmaxf(tb, tt);
+    } else if (origin >= 0.0f && origin < size) {
+        in_is_low = true;
+        tin = -RT_INF; tout = RT_INF;
+    } else {
+        in_is_low = true;
+        tin = RT_INF; tout = -RT_INF;
+    }
+}
+
+// Impl/RenderableImpl.h:89-255 (local frame: axis +y, base at the origin).  Tube
+// coefficients from the xz components alone: a = d.x^2 + d.z^2 equals d.d - d.y^2
+// (Hittable.swift:264) without the cancellation.
+RT_DEV Span cylinder_span(const XPrim &x, f3 o, f3 d) {
+    float radius = x.p0, height = x.p1;
+    f3 lo = rot_t(x, o - x.t), ld = rot_t(x, d);
+    float p_in, p_out;
+    bool low;
+    slab(height, lo.y, ld.y, p_in, p_out, low);
+    uint32_t p_in_tag = low ? 0u : 1u, p_out_tag = low ? 1u : 0u;
+
+    float t_in, t_out;
+    float a = fmaf(ld.x, ld.x, ld.z * ld.z);
+    float b = fmaf(ld.x, lo.x, ld.z * lo.z);
+    float oo = fmaf(lo.x, lo.x, lo.z * lo.z);
+    bool parallel = true;
+    t_in = RT_INF; t_out = -RT_INF;
+    if (a > 0.0f) {
+        float inv_a = rcp(a);
+        float ba = b * inv_a;
+        float lx = fmaf(-ba, ld.x, lo.x), lz = fmaf(-ba, ld.z, lo.z);
+        float h = fmaf(radius, radius, -fmaf(lx, lx, lz * lz));
+        if (h < 0.0f) {
+            parallel = false;      // D < 0: no intersection with the tube
+        } else {
+            float root = fsqrt(h * a);
+            float t1 = (-b - root) * inv_a, t2 = (-b + root) * inv_a;
+            if (finite(t1) && finite(t2)) { t_in = t1; t_out = t2; parallel = false; }
+        }
+    }
+    if (parallel) {   // RenderableImpl.h:190-200
+        if (oo > radius * radius) { t_in = RT_INF; t_out = -RT_INF; }
+        else { t_in = -RT_INF; t_out = RT_INF; }
+    }
+    Span sp;
+    if (p_in > t_in) { sp.t0 = p_in; sp.tag0 = p_in_tag; } else { sp.t0 = t_in; sp.tag0 = 2u; }       // :222
+    if (p_out < t_out) { sp.t1 = p_out; sp.tag1 = p_out_tag; } else { sp.t1 = t_out; sp.tag1 = 2u; }  // :223
+    return sp;
+}
+
+// Impl/RenderableImpl.h:257-334 (box [0,size] in the local frame).
+RT_DEV Span cuboid_span(const XPrim &x, f3 o, f3 d) {
+    f3 lo = rot_t(x, o - x.t), ld = rot_t(x, d);
+    float xi, xo, yi, yo, zi, zo;
+    bool xl, yl, zl;
+    slab(x.p0, lo.x, ld.x, xi, xo, xl);
+    slab(x.p1, lo.y, ld.y, yi, yo, yl);
+    slab(x.p2, lo.z, ld.z, zi, zo, zl);
+    uint32_t xin = xl ? 0u : 1u, yin = yl ? 2u : 3u, zin = zl ? 4u : 5u;
+    Span sp;
+    // :331-332, ties go to the later axis
+    if (xi > yi) { if (xi > zi) { sp.t0 = xi; sp.tag0 = xin; } else { sp.t0 = zi; sp.tag0 = zin; } }
+    else { if (yi > zi) { sp.t0 = yi; sp.tag0 = yin; } else { sp.t0 = zi; sp.tag0 = zin; } }
+    if (xo < yo) { if (xo < zo) { sp.t1 = xo; sp.tag1 = xin ^ 1u; } else { sp.t1 = zo; sp.tag1 = zin ^ 1u; } }
+    else { if (yo < zo) { sp.t1 = yo; sp.tag1 = yin ^ 1u; } else { sp.t1 = zo; sp.tag1 = zin ^ 1u; } }
+    return sp;
+}
+
+// Impl/RenderableImpl.h:395-436: the quad as the half space behind its plane, cut to
+// the parallelogram.  Record: origin (c0), u (c1), v (c2), w (t), normal (p0..p2), d (p3).
+RT_DEV Span quad_span(const XPrim &x, f3 o, f3 d, float &alpha, float &beta) {
+    f3 normal = mk3(x.p0, x.p1, x.p2);
+    float denom = dot(d, normal);
+    float t = (x.p3 - dot(o, normal)) * rcp(denom);
+    Span sp = empty_span();
+    alpha = beta = 0.0f;
+    if (finite(t)) {
+        f3 p = madd(d, t, o) - x.c0;
+        alpha = dot(x.t, cross(p, x.c2));
+        beta = dot(x.t, cross(x.c1, p));
+        if (!(alpha < 0.0f || alpha > 1.0f || beta < 0.0f || beta > 1.0f)) {
+            sp.t0 = denom < 0.0f ? t : -RT_INF;
+            sp.t1 = denom < 0.0f ? RT_INF : t;
+        }
+    }
+    return sp;
+}
+
+RT_DEV Span prim_span(const RtDevScene &s, uint32_t ref, f3 o, f3 d) {
+    uint32_t kind = (ref >> RT_KIND_SHIFT) & 7u, idx = ref & RT_INDEX_MASK;
+    if (kind == RT_KIND_SPHERE) return sphere_span(s, idx, o, d);
+    XPrim x = load_xprim(s, idx);
+    if (kind == RT_KIND_CYLINDER) return cylinder_span(x, o, d);
+    if (kind == RT_KIND_CUBOID) return cuboid_span(x, o, d);
+    float al, be;
+    return quad_span(x, o, d, al, be);
+}
+
+// ------------------------------------------------------------------ hit completion
+struct Surface {
+    f3 normal;          // as enumerated by the reference (not flipped against the ray)
+    float u, v;
+    uint32_t material;
+};
+
+// Attributes of the boundary of primitive `ref` at parameter t on surface `tag`:
+// normals and texture coordinates of RenderableImpl.h:72-86 (sphere), :113-121,141-146,
+// 181-189,203-208 (cylinder), :350-392 (cuboid), :418-426 (quad).
+RT_DEV Surface prim_surface(const RtDevScene &s, uint32_t ref, uint32_t tag, f3 o, f3 d, float t, bool want_uv) {
+    uint32_t kind = (ref >> RT_KIND_SHIFT) & 7u, idx = ref & RT_INDEX_MASK;
+    Surface r;
+    r.u = r.v = 0.0f;
+    f3 p = madd(d, t, o);
+    if (kind == RT_KIND_SPHERE) {
+        float4 g = ((const float4 *)s.spheres)[idx];
+        r.normal = (p - mk3(g.x, g.y, g.z)) * rcp(g.w);
+        r.material = s.sphere_mat[idx];
+        if (want_uv) {
+            f3 n = r.normal;
+            if (s.sphere_rot) {
+                const float4 *q = (const float4 *)s.sphere_rot + 3u * idx;
+                float4 a = q[0], b = q[1], c = q[2];
+                n = mk3(dot(mk3(a.x, a.y, a.z), r.normal), dot(mk3(b.x, b.y, b.z), r.normal), dot(mk3(c.x, c.y, c.z), r.normal));
+            }
+            r.u = (atan2f(n.z, -n.x) + RT_PI) * (1.0f / (2.0f * RT_PI));
+            r.v = acosf(fminf(fmaxf(-n.y, -1.0f), 1.0f)) * (1.0f / RT_PI);
+        }
+        return r;
+    }
+    XPrim x = load_xprim(s, idx);
+    const uint32_t *mats = s.xprim_mat + 6u * idx;
+    if (kind == RT_KIND_CYLINDER) {
+        float radius = x.p0, height = x.p1;
+        f3 lp = rot_t(x, p - x.t);
+        if (tag == 2u) {
+            r.normal = rot(x, mk3(lp.x, 0.0f, lp.z) * rcp(radius));
+            r.material = mats[2];
+            if (want_uv) {
+                r.u = (atan2f(lp.z, -lp.x) + RT_PI) * (1.0f / (2.0f * RT_PI));
+                r.v = lp.y * rcp(height);
+            }
+        } else {
+            float flip = tag == 0u ? -1.0f : 1.0f;
+            r.normal = x.c1 * flip;
+            r.material = mats[tag];
+            float inv2r = rcp(2.0f * radius);
+            r.u = fmaf(lp.z * flip, inv2r, 0.5f);
+            r.v = fmaf(lp.x, inv2r, 0.5f);
+        }
+        return r;
+    }
+    if (kind == RT_KIND_CUBOID) {
+        uint32_t axis = tag >> 1;
+        f3 col = axis == 0u ? x.c0 : (axis == 1u ? x.c1 : x.c2);
+        r.normal = (tag & 1u) ? col : -col;
+        r.material = mats[tag];
+        f3 lp = rot_t(x, p - x.t) * mk3(rcp(x.p0), rcp(x.p1), rcp(x.p2));
+        switch (tag) {
+        case 0: r.u = 1.0f - lp.z; r.v = lp.y; break;          // left
+        case 1: r.u = lp.z; r.v = lp.y; break;                 // right
+        case 2: r.u = lp.x; r.v = 1.0f - lp.z; break;          // bottom
+        case 3: r.u = lp.x; r.v = lp.z; break;                 // top
+        case 4: r.u = 1.0f - lp.x; r.v = lp.y; break;          // back
+        default: r.u = lp.x; r.v = lp.y; break;                // front
+        }
+        return r;
+    }
+    // quad
+    r.normal = mk3(x.p0, x.p1, x.p2);
+    r.material = mats[0];
+    f3 q = p - x.c0;
+    r.u = dot(x.t, cross(q, x.c2));
+    r.v = dot(x.t, cross(x.c1, q));
+    return r;
+}
+
+// ------------------------------------------------------------------ CSG: interval-list evaluation
+// A CSG shape is flattened on the host to its leaf primitives plus a truth table: bit m
+// of `truth` says whether a point that lies inside exactly the leaves of mask m lies
+// inside the shape.  Walking the leaf interval ends in increasing t (ties: the leaf with
+// the larger index first, which is what the reference's nested merges do,
+// RenderableImpl.h:532-548) and looking the mask up after each step yields the shape's own
+// entry/exit events: wherever the looked-up bit changes.  This reproduces the depth
+// counting of RenderableImpl.h:678-691 for Union / Intersection / Subtract at any nesting.
+struct CsgIter {
+    float tin[RT_CSG_LEAVES], tout[RT_CSG_LEAVES];
+    uint64_t tags;            // 3 bits entry tag + 3 bits exit tag per leaf
+    uint32_t n, entered, exited, flip;
+    uint32_t truth[8];
+    bool inside;
+    // current event
+    float t;
+    uint32_t leaf, tag;
+    bool is_exit, leaf_exit;
+};
+
+RT_DEV bool csg_lookup(const CsgIter &it, uint32_t mask) { return (it.truth[mask >> 5] >> (mask & 31u)) & 1u; }
+
+RT_DEV void csg_begin(const RtDevScene &s, uint32_t idx, f3 o, f3 d, CsgIter &it) {
+    const RtDevCsg &c = s.csg[idx];
+    it.n = c.n_leaves;
+    it.flip = c.flip_mask;
+    it.tags = 0;
+    it.entered = it.exited = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) it.truth[i] = c.truth[i];
+#pragma unroll
+    for (int i = 0; i < RT_CSG_LEAVES; i++) { it.tin[i] = RT_INF; it.tout[i] = RT_INF; }
+    for (uint32_t i = 0; i < it.n; i++) {
+        Span sp = prim_span(s, c.leaf[i], o, d);
+        bool ok = span_valid(sp);
+        float a = ok ? sp.t0 : RT_INF, b = ok ? sp.t1 : RT_INF;
+#pragma unroll
+        for (int j = 0; j < RT_CSG_LEAVES; j++) {
+            if (j == (int)i) { it.tin[j] = a; it.tout[j] = b; }
+        }
+        it.tags |= (uint64_t)(sp.tag0 | (sp.tag1 << 3)) << (6u * i);
+        if (!ok) { it.entered |= 1u << i; it.exited |= 1u << i; }     // nothing left to visit
+    }
+    it.inside = csg_lookup(it, 0u);
+}
+
+// Advances to the next event of the shape; false when none is left.  An end at +inf is
+// never reached (the reference's merge cannot select it either, RenderableImpl.h:538).
+RT_DEV bool csg_next(CsgIter &it) {
+    while (true) {
+        float best = RT_INF;
+        int who = -1;
+#pragma unroll
+        for (int j = RT_CSG_LEAVES - 1; j >= 0; j--) {
+            bool ent = (it.entered >> j) & 1u, ext = (it.exited >> j) & 1u;
+            float cand = ext ? RT_INF : (ent ? it.tout[j] : it.tin[j]);
+            if (cand < best) { best = cand; who = j; }
+        }
+        if (who < 0) return false;
+        bool leaf_exit = (it.entered >> who) & 1u;
+        if (leaf_exit) it.exited |= 1u << who; else it.entered |= 1u << who;
+        uint32_t mask = it.entered & ~it.exited;
+        bool now = csg_lookup(it, mask);
+        if (now != it.inside) {
+            it.inside = now;
+            it.t = best;
+            it.leaf = (uint32_t)who;
+            it.leaf_exit = leaf_exit;
+            it.is_exit = !now;
+            it.tag = (uint32_t)(it.tags >> (6u * who + (leaf_exit ? 3u : 0u))) & 7u;
+            return true;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ closest hit of one object
+// What extend remembers about the closest hit; `code` lets shade rebuild the surface:
+//   primitive        tag
+//   CSG              tag | leaf << 3 | leaf_exit << 6
+//   volume (CDV)     bit 31 set = scatter inside the medium; low bits = the base's code for
+//                    the entry event (scatter) or the exit event (boundary)
+struct Best { float t; uint32_t ref, code; };
+
+#define RT_CODE_SCATTER 0x80000000u
+#define RT_CODE_INTERVAL_SHIFT 8
+
+// Accept rule of Shaders.metal:182-199 for one candidate distance.
+RT_DEV bool in_range(float t, float tmin, float tmax_incl, bool found, float best) {
+    return t >= tmin && (found ? t < best : t <= tmax_incl);
+}
+
+template <bool SIMPLE>
+RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmin, float tmax, uint64_t volume_key,
+                        const float *scripted, uint32_t n_scripted, bool &found, Best &best) {
+    uint32_t kind = (ref >> RT_KIND_SHIFT) & 7u, idx = ref & RT_INDEX_MASK;
+    if (SIMPLE || kind == RT_KIND_SPHERE) {
+        Span sp = sphere_span(s, idx, o, d);
+        if (span_valid(sp)) {
+            if (in_range(sp.t0, tmin, tmax, found, best.t)) { best.t = sp.t0; best.ref = ref; best.code = 0; found = true; }
+            else if (in_range(sp.t1, tmin, tmax, found, best.t)) { best.t = sp.t1; best.ref = ref; best.code = 0; found = true; }
+        }
+        return;
+    }
+    if (kind <= RT_KIND_QUAD) {
+        Span sp = prim_span(s, ref, o, d);
+        if (span_valid(sp)) {
+            if (in_range(sp.t0, tmin, tmax, found, best.t)) { best.t = sp.t0; best.ref = ref; best.code = sp.tag0; found = true; }
+            else if (in_range(sp.t1, tmin, tmax, found, best.t)) { best.t = sp.t1; best.ref = ref; best.code = sp.tag1; found = true; }
+        }
+        return;
+    }
+    if (kind == RT_KIND_CSG) {
+        CsgIter it;
+        csg_begin(s, idx, o, d, it);
+        while (csg_next(it)) {
+            if (in_range(it.t, tmin, tmax, found, best.t)) {
+                best.t = it.t; best.ref = ref;
+                best.code = it.tag | (it.leaf << 3) | ((it.leaf_exit ? 1u : 0u) << 6);
+                found = true;
+                break;
+            }
+            if (found && it.t >= best.t) break;
+        }
+        return;
+    }
+    // Constant-density volume, RenderableImpl.h:737-777: one free-flight draw per interval of
+    // the base shape; a scatter inside the interval is followed by the interval's exit.
+    const RtDevCdv cv = s.cdv[idx];
+    Pcg vr = pcg_seed(volume_key, (uint64_t)(s.cdv_obj[idx] + 1u));
+    uint32_t draw = 0;
+    uint32_t bkind = (cv.base >> RT_KIND_SHIFT) & 7u;
+    if (bkind != RT_KIND_CSG) {
+        Span sp = prim_span(s, cv.base, o, d);
+        if (!span_valid(sp)) return;
+        float t1 = fmaxf(0.0f, sp.t0), t2 = sp.t1;
+        if (!(t1 < t2)) return;
+        float u = scripted ? scripted[draw % n_scripted] : rnd(vr);
+        float t = fmaf(logf(1.0f - u), cv.neg_inv_density, t1);
+        if (!(t <= t2)) return;
+        if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = ref; best.code = RT_CODE_SCATTER | sp.tag0; found = true; }
+        else if (in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = ref; best.code = sp.tag1; found = true; }
+        return;
+    }
+    CsgIter it;
+    csg_begin(s, cv.base & RT_INDEX_MASK, o, d, it);
+    uint32_t interval = 0;
+    while (csg_next(it)) {
+        float t_entry = it.t;
+        uint32_t entry_code = it.tag | (it.leaf << 3) | ((it.leaf_exit ? 1u : 0u) << 6);
+        float t2 = RT_INF;
+        uint32_t exit_code = 0;
+        bool has_exit = csg_next(it);
+        if (has_exit) { t2 = it.t; exit_code = it.tag | (it.leaf << 3) | ((it.leaf_exit ? 1u : 0u) << 6); }
+        float t1 = fmaxf(0.0f, t_entry);
+        if (t1 < t2) {
+            float u = scripted ? scripted[draw % n_scripted] : rnd(vr);
+            draw++;
+            float t = fmaf(logf(1.0f - u), cv.neg_inv_density, t1);
+            if (t <= t2) {
+                uint32_t iv = interval << RT_CODE_INTERVAL_SHIFT;
+                if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = ref; best.code = RT_CODE_SCATTER | iv | entry_code; found = true; return; }
+                if (has_exit && in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = ref; best.code = iv | exit_code; found = true; return; }
+            }
+        }
+        if (!has_exit) return;
+        interval++;
+    }
+}
+
+// ------------------------------------------------------------------ BVH traversal (extend)
+// Node: 16 floats = left box (min xyz, max xyz), right box, left ref, right ref, 2 pad.
+// A reference with RT_REF_LEAF set names an object (kind | index), otherwise a node.
+// The per-lane stack lives in LDS as stack[entry * RT_BLOCK + lane]: the 64 lanes of a
+// wave hit 64 consecutive banks whatever their individual depth.
+RT_DEV float box_entry(f3 bmin, f3 bmax, f3 o, f3 inv_d, float tmin, float tmax, bool &hit) {
+    float tx0 = (bmin.x - o.x) * inv_d.x, tx1 = (bmax.x - o.x) * inv_d.x;
+    float ty0 = (bmin.y - o.y) * inv_d.y, ty1 = (bmax.y - o.y) * inv_d.y;
+    float tz0 = (bmin.z - o.z) * inv_d.z, tz1 = (bmax.z - o.z) * inv_d.z;
+    // fminf/fmaxf drop a NaN operand (0 * inf on an axis-parallel ray lying in a box plane)
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
+    hit = tn <= tf;
+    return tn;
+}
+
+template <bool SIMPLE>
+RT_DEV bool trace(const RtDevScene &s, f3 o, f3 d, float tmin, float tmax, uint64_t volume_key,
+                  const float *scripted, uint32_t n_scripted, uint32_t *stack, Best &best) {
+    bool found = false;
+    best.t = tmax;
+    best.ref = RT_REF_NONE;
+    best.code = 0;
+    uint32_t cur = s.root;
+    if (cur == RT_REF_NONE) return false;
+    f3 inv_d = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
+    int sp = 0;
+    const float4 *nodes = (const float4 *)s.nodes;
+    while (true) {
+        while (!(cur & RT_REF_LEAF)) {
+            const float4 *n = nodes + 4u * cur;
+            float4 a = n[0], b = n[1], c = n[2], e = n[3];
+            bool hl, hr;
+            // a box farther than the closest hit so far cannot hold a closer one
+            float limit = best.t;
+            float tl = box_entry(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), o, inv_d, tmin, limit, hl);
+            float tr = box_entry(mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), o, inv_d, tmin, limit, hr);
+            uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
+            hl = hl && lref != RT_REF_NONE;
+            hr = hr && rref != RT_REF_NONE;
+            if (hl && hr) {
+                bool left_first = tl <= tr;
+                uint32_t nearer = left_first ? lref : rref, farther = left_first ? rref : lref;
+                stack[sp * RT_BLOCK] = farther;
+                sp++;
+                cur = nearer;
+            } else if (hl) {
+                cur = lref;
+            } else if (hr) {
+                cur = rref;
+            } else {
+                if (sp == 0) return found;
+                sp--;
+                cur = stack[sp * RT_BLOCK];
+            }
+        }
+        test_object<SIMPLE>(s, cur & ~RT_REF_LEAF, o, d, tmin, tmax, volume_key, scripted, n_scripted, found, best);
+        if (sp == 0) return found;
+        sp--;
+        cur = stack[sp * RT_BLOCK];
+    }
+}
+
+// ------------------------------------------------------------------ surface of the closest hit
+struct HitRecord {
+    f3 point, normal;      // normal flipped to oppose the ray (HitTesting.h:24-32)
+    float u, v;
+    uint32_t material;
+    uint32_t object;
+    bool front;
+};
+
+RT_DEV Surface csg_surface(const RtDevScene &s, uint32_t csg_idx, uint32_t code, f3 o, f3 d, float t, bool want_uv) {
+    const RtDevCsg &c = s.csg[csg_idx];
+    uint32_t leaf = (code >> 3) & 7u;
+    Surface sf = prim_surface(s, c.leaf[leaf], code & 7u, o, d, t, want_uv);
+    if ((c.flip_mask >> leaf) & 1u) sf.normal = -sf.normal;      // RenderableImpl.h:712
+    return sf;
+}
+
+// Re-finds interval number `interval` of a CSG base and returns its entry distance and code.
+RT_DEV void csg_entry_of_interval(const RtDevScene &s, uint32_t csg_idx, f3 o, f3 d, uint32_t interval, float &t, uint32_t &code) {
+    CsgIter it;
+    csg_begin(s, csg_idx, o, d, it);
+    t = 0.0f; code = 0;
+    for (uint32_t k = 0; csg_next(it); k++) {
+        if (k == 2u * interval) {
+            t = it.t;
+            code = it.tag | (it.leaf << 3) | ((it.leaf_exit ? 1u : 0u) << 6);
+            return;
+        }
+    }
+}
+
+RT_DEV void complete_hit(const RtDevScene &s, const Best &best, f3 o, f3 d, bool want_uv, HitRecord &h) {
+    uint32_t kind = (best.ref >> RT_KIND_SHIFT) & 7u, idx = best.ref & RT_INDEX_MASK;
+    Surface sf;
+    h.point = madd(d, best.t, o);
+    if (kind == RT_KIND_SPHERE) {
+        sf = prim_surface(s, best.ref, 0, o, d, best.t, want_uv);
+        h.object = s.sphere_obj[idx];
+    } else if (kind <= RT_KIND_QUAD) {
+        sf = prim_surface(s, best.ref, best.code & 7u, o, d, best.t, want_uv);
+        h.object = s.xprim_obj[idx];
+    } else if (kind == RT_KIND_CSG) {
+        sf = csg_surface(s, idx, best.code, o, d, best.t, want_uv);
+        h.object = s.csg_obj[idx];
+    } else {
+        const RtDevCdv cv = s.cdv[idx];
+        h.object = s.cdv_obj[idx];
+        uint32_t bkind = (cv.base >> RT_KIND_SHIFT) & 7u;
+        bool scatter = best.code & RT_CODE_SCATTER;
+        if (!scatter) {
+            // boundary exit of the base shape
+            if (bkind == RT_KIND_CSG) sf = csg_surface(s, cv.base & RT_INDEX_MASK, best.code, o, d, best.t, want_uv);
+            else sf = prim_surface(s, cv.base, best.code & 7u, o, d, best.t, want_uv);
+        } else {
+            // RenderableImpl.h:760-766: point on the ray, normal against the ray, material and
+            // texture coordinates of the ENTRY hit of the interval
+            if (bkind == RT_KIND_CSG) {
+                float te; uint32_t ce;
+                csg_entry_of_interval(s, cv.base & RT_INDEX_MASK, o, d, (best.code & 0x7FFFFFFFu) >> RT_CODE_INTERVAL_SHIFT, te, ce);
+                sf = csg_surface(s, cv.base & RT_INDEX_MASK, ce, o, d, te, true);
+            } else {
+                Span sp = prim_span(s, cv.base, o, d);
+                sf = prim_surface(s, cv.base, best.code & 7u, o, d, sp.t0, true);
+            }
+            sf.normal = -d;
+        }
+    }
+    h.u = sf.u; h.v = sf.v;
+    h.material = sf.material;
+    if (dot(sf.normal, d) > 0.0f) { h.normal = -sf.normal; h.front = false; }
+    else { h.normal = sf.normal; h.front = true; }
+}
+
+// ------------------------------------------------------------------ materials (shade)
+// Material record: 8 floats = kind, texture id, fuzz, refraction index, albedo rgb, pad.
+struct Material { uint32_t kind, texture; float fuzz, ior; f3 albedo; };
+RT_DEV Material load_material(const RtDevScene &s, uint32_t id) {
+    const float4 *q = (const float4 *)s.materials + 2u * id;
+    float4 a = q[0], b = q[1];
+    Material m;
+    m.kind = __float_as_uint(a.x);
+    m.texture = __float_as_uint(a.y);
+    m.fuzz = a.z;
+    m.ior = a.w;
+    m.albedo = mk3(b.x, b.y, b.z);
+    return m;
+}
+RT_DEV bool material_wants_uv(uint32_t kind) { return kind == 2u || kind == 5u; }
+
+// MaterialsImpl.h:53-58: normalised coordinates, nearest texel, clamp to edge; v = 0 is the
+// bottom row (the loader's bottom-left origin), rows are stored top to bottom.
+RT_DEV f3 sample_image(const RtDevScene &s, uint32_t tex, float u, float v) {
+    RtDevTexture t = s.textures[tex];
+    int x = (int)floorf(u * (float)t.width), y = (int)floorf(v * (float)t.height);
+    x = min(max(x, 0), (int)t.width - 1);
+    y = min(max(y, 0), (int)t.height - 1);
+    uint32_t px = s.texels[t.offset + (t.height - 1u - (uint32_t)y) * t.width + (uint32_t)x];
+    return mk3((float)(px & 255u), (float)((px >> 8) & 255u), (float)((px >> 16) & 255u)) * (1.0f / 255.0f);
+}
+
+RT_DEV float mixf(float a, float b, float t) { return fmaf(b - a, t, a); }
+
+// MaterialsImpl.h:60-121
+RT_DEV float perlin_noise(const RtDevPerlin &tex, f3 p) {
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    int xi0 = ((int)fx) & 255, yi0 = ((int)fy) & 255, zi0 = ((int)fz) & 255;
+    int xi1 = (xi0 + 1) & 255, yi1 = (yi0 + 1) & 255, zi1 = (zi0 + 1) & 255;
+    float tx = p.x - fx, ty = p.y - fy, tz = p.z - fz;
+    float u = tx * tx * tx * (tx * (6.0f * tx - 15.0f) + 10.0f);
+    float v = ty * ty * ty * (ty * (6.0f * ty - 15.0f) + 10.0f);
+    float w = tz * tz * tz * (tz * (6.0f * tz - 15.0f) + 10.0f);
+    int hx0 = tex.permutations[0][xi0], hx1 = tex.permutations[0][xi1];
+    int h00 = tex.permutations[1][(hx0 + yi0) & 255], h10 = tex.permutations[1][(hx1 + yi0) & 255];
+    int h01 = tex.permutations[1][(hx0 + yi1) & 255], h11 = tex.permutations[1][(hx1 + yi1) & 255];
+    float x0 = tx, x1 = tx - 1.0f, y0 = ty, y1 = ty - 1.0f, z0 = tz, z1 = tz - 1.0f;
+#define RT_GRAD(h, zi, X, Y, Z) (dot(ld3(tex.vectors[tex.permutations[2][((h) + (zi)) & 255]]), mk3(X, Y, Z)))
+    float a = mixf(RT_GRAD(h00, zi0, x0, y0, z0), RT_GRAD(h10, zi0, x1, y0, z0), u);
+    float b = mixf(RT_GRAD(h01, zi0, x0, y1, z0), RT_GRAD(h11, zi0, x1, y1, z0), u);
+    float c = mixf(RT_GRAD(h00, zi1, x0, y0, z1), RT_GRAD(h10, zi1, x1, y0, z1), u);
+    float e = mixf(RT_GRAD(h01, zi1, x0, y1, z1), RT_GRAD(h11, zi1, x1, y1, z1), u);
+#undef RT_GRAD
+    return mixf(mixf(a, b, v), mixf(c, e, v), w);
+}
+
+// MaterialsImpl.h:123-139
+RT_DEV f3 perlin_color(const RtDevScene &s, uint32_t id, f3 point) {
+    const RtDevPerlin &tex = s.perlin[id];
+    float t = 0.0f;
+    if (tex.turbulence == 0u) {
+        t = 1.0f + perlin_noise(tex, point * tex.frequency);
+    } else {
+        float f = tex.frequency, weight = 1.0f;
+        for (uint32_t i = 0; i < tex.turbulence; i++) {
+            t = fmaf(perlin_noise(tex, point * f), weight, t);
+            weight *= 0.5f;
+            f *= 2.0f;
+        }
+        t = fabsf(t);
+    }
+    f3 c0 = ld3(tex.colors[0]), c1 = ld3(tex.colors[1]);
+    return madd(c1 - c0, t, c0);
+}
+
+RT_DEV f3 material_color(const RtDevScene &s, const Material &m, const HitRecord &h) {
+    if (m.kind == 2u || m.kind == 5u) return sample_image(s, m.texture, h.u, h.v);
+    if (m.kind == 3u || m.kind == 6u) return perlin_color(s, m.texture, h.point);
+    return m.albedo;
+}
+
+// MaterialsImpl.h:16-24
+RT_DEV float schlick(float cos_theta, float eta) {
+    float sq = (1.0f - eta) * rcp(1.0f + eta);
+    float r0 = sq * sq;
+    float x = 1.0f + cos_theta;
+    float x2 = x * x;
+    return fmaf(1.0f - r0, x2 * x2 * x, r0);
+}
+
+// One scattering event, MaterialsImpl.h:147-215.  Returns false when the path ends here
+// (emissive surface, or metal absorbing a reflection that points below the surface).
+RT_DEV bool scatter(const RtDevScene &s, const Material &m, f3 d, const HitRecord &h, Pcg &g,
+                    f3 &emitted, f3 &attenuation, f3 &new_d) {
+    emitted = mk3(0, 0, 0);
+    attenuation = mk3(0, 0, 0);
+    switch (m.kind) {
+    case 1: case 2: case 3: {      // lambertian
+        while (true) {
+            f3 v = h.normal + random_unit_vector_3d(g);
+            float len_sq = dot(v, v);
+            if (len_sq > RT_MIN_LEN_SQ) { new_d = v * __builtin_amdgcn_rsqf(len_sq); break; }
+        }
+        attenuation = material_color(s, m, h);
+        return true;
+    }
+    case 4: case 5: case 6: {      // metal
+        f3 refl = madd(h.normal, -2.0f * dot(d, h.normal), d);
+        refl = madd(random_unit_vector_3d(g), m.fuzz, refl);
+        if (dot(refl, h.normal) < 0.0f) return false;
+        attenuation = material_color(s, m, h);
+        new_d = normalize3(refl);
+        return true;
+    }
+    case 7: {                      // dielectric, MaterialsImpl.h:26-47,173-180
+        float eta = h.front ? rcp(m.ior) : m.ior;
+        float u = rnd(g);
+        float cos_theta = fmaxf(dot(d, h.normal), -1.0f);
+        f3 r_perp = madd(h.normal, -cos_theta, d) * eta;
+        float perp_sq = dot(r_perp, r_perp);
+        bool refracts = !(perp_sq > 1.0f) && !(u <= 0.0f) && !(u < 1.0f && schlick(cos_theta, eta) > u);
+        if (refracts) new_d = madd(h.normal, -fsqrt(1.0f - perp_sq), r_perp);
+        else new_d = madd(h.normal, -2.0f * dot(d, h.normal), d);
+        attenuation = mk3(1, 1, 1);
+        return true;
+    }
+    case 8:                        // emissive
+        emitted = m.albedo;
+        return false;
+    default:                       // isotropic
+        new_d = random_unit_vector_3d(g);
+        attenuation = m.albedo;
+        return true;
+    }
+}

@@ -1,0 +1,829 @@
+// rt_host.cpp - host side of the C ABI (include/raytracer_amd.h): scene description,
+// flattening into device buffers, BVH build, and the entry points that launch kernels.
+//
+// Flattening replaces MetalRayTracer/SceneBuffers.swift:15-72: instead of one AoS buffer per
+// concrete Swift type it writes structure-of-arrays streams split by what each stage reads
+// (see rt_shared.h).  The BVH follows RayTracingKit/Hittable.swift:609-631: longest axis
+// of the node's box (ties as AABB.swift:59-66), objects ordered by box centre on that
+// axis, split at (n+1)/2 - linearised into 64-byte nodes that carry both child boxes.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/raytracer_amd.h"
+#include "rt_launch.h"
+#include "rt_shared.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+int fail_hip(hipError_t e, const char *what) {
+    g_error = std::string(what) + ": " + hipGetErrorString(e);
+    return RT_ERR_DEVICE;
+}
+
+struct Box3 {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    void add(const float p[3]) { for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], p[a]); mx[a] = std::max(mx[a], p[a]); } }
+    void add(const Box3 &b) { add(b.mn); add(b.mx); }
+};
+
+struct HostShape {
+    uint32_t kind = 0;
+    float rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, trans[3] = {0, 0, 0};
+    float radius = 0, height = 0, size[3] = {0, 0, 0};
+    float quad[16] = {0};
+    uint32_t mat[6] = {0, 0, 0, 0, 0, 0};
+    int op = 0;
+    std::vector<int> children;
+    int base = -1;
+    float density = 0;
+    int parent = -1;        // CSG / volume that uses this shape, -1 if none
+    int object = -1;        // scene object made of this shape, -1 if none
+    uint32_t ref = RT_REF_NONE;
+    Box3 box;
+};
+
+struct HostTexture { int w, h; std::vector<uint32_t> rgba; };
+
+}  // namespace
+
+struct RtContext {
+    int device = 0;
+    int cus = 256;
+};
+
+struct RtScene {
+    RtContext *ctx = nullptr;
+    std::vector<HostShape> shapes;
+    std::vector<int> objects;
+    std::vector<float> materials;          // 8 floats each
+    std::vector<uint32_t> material_kinds;
+    std::vector<HostTexture> textures;
+    std::vector<RtDevPerlin> perlin;
+    // bulk spheres (kept as arrays: a million HostShape records would be wasteful)
+    std::vector<float> bulk_spheres;       // cx, cy, cz, r
+    std::vector<uint32_t> bulk_mats;
+    bool committed = false;
+    std::vector<void *> device_allocs;
+    RtDevScene dev{};
+    uint32_t feat = 0;
+    RtSceneStats stats{};
+    RtKernelTimer timer;
+
+    ~RtScene() { release(); }
+    void release() {
+        for (void *p : device_allocs) (void)hipFree(p);
+        device_allocs.clear();
+    }
+};
+
+namespace {
+
+template <class T> int upload(RtScene *sc, const std::vector<T> &v, const T **out) {
+    *out = nullptr;
+    if (v.empty()) return RT_OK;
+    void *p = nullptr;
+    size_t bytes = v.size() * sizeof(T);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc");
+    sc->device_allocs.push_back(p);
+    e = hipMemcpy(p, v.data(), bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail_hip(e, "hipMemcpy");
+    sc->stats.device_bytes += bytes;
+    *out = (const T *)p;
+    return RT_OK;
+}
+
+void xform(const HostShape &s, const float p[3], float out[3]) {
+    for (int r = 0; r < 3; r++) out[r] = s.rot[r] * p[0] + s.rot[3 + r] * p[1] + s.rot[6 + r] * p[2] + s.trans[r];
+}
+
+// Bounding boxes: Primitives.swift:29-33 (sphere), :112-125 (cylinder, disk formula),
+// :163-180 (cuboid corners), :253-260 (quad corners); CSG.swift:21-23 (subtract = lhs),
+// :60-66 (union), :102-108 (intersection); ConstantDensityVolume.swift:21-23.
+Box3 shape_box(const RtScene &sc, int id) {
+    const HostShape &s = sc.shapes[id];
+    Box3 b;
+    switch (s.kind) {
+    case RT_KIND_SPHERE:
+        for (int a = 0; a < 3; a++) { b.mn[a] = s.trans[a] - s.radius; b.mx[a] = s.trans[a] + s.radius; }
+        break;
+    case RT_KIND_CYLINDER: {
+        const float *n = s.rot + 3;
+        for (int a = 0; a < 3; a++) {
+            float rp = std::sqrt(std::max(0.f, 1.f - n[a] * n[a])) * s.radius;
+            float bc = s.trans[a], tc = s.trans[a] + s.height * n[a];
+            b.mn[a] = std::min(bc, tc) - rp;
+            b.mx[a] = std::max(bc, tc) + rp;
+        }
+        break;
+    }
+    case RT_KIND_CUBOID:
+        for (int i = 0; i < 8; i++) {
+            float p[3] = {(i & 1) ? s.size[0] : 0.f, (i & 2) ? s.size[1] : 0.f, (i & 4) ? s.size[2] : 0.f}, w[3];
+            xform(s, p, w);
+            b.add(w);
+        }
+        break;
+    case RT_KIND_QUAD:
+        for (int i = 0; i < 4; i++) {
+            float p[3];
+            for (int a = 0; a < 3; a++) p[a] = s.quad[a] + ((i & 1) ? s.quad[3 + a] : 0.f) + ((i & 2) ? s.quad[6 + a] : 0.f);
+            b.add(p);
+        }
+        break;
+    case RT_KIND_CSG:
+        if (s.op == RT_CSG_SUBTRACT) {
+            b = shape_box(sc, s.children[0]);
+        } else if (s.op == RT_CSG_UNION) {
+            for (int c : s.children) b.add(shape_box(sc, c));
+        } else {
+            for (int a = 0; a < 3; a++) { b.mn[a] = -INFINITY; b.mx[a] = INFINITY; }
+            for (int c : s.children) {
+                Box3 cb = shape_box(sc, c);
+                for (int a = 0; a < 3; a++) { b.mn[a] = std::max(b.mn[a], cb.mn[a]); b.mx[a] = std::min(b.mx[a], cb.mx[a]); }
+            }
+        }
+        break;
+    default:
+        b = shape_box(sc, s.base);
+        break;
+    }
+    return b;
+}
+
+// Boxes are widened a little: a flat box (axis-aligned quad) gets thickness, and every box
+// a few float ulps, so that rounding in the slab test can never cull a hit the primitive
+// test would accept.
+void pad_box(Box3 &b) {
+    for (int a = 0; a < 3; a++) {
+        if (!(b.mn[a] <= b.mx[a])) continue;    // empty (e.g. disjoint intersection): leave it
+        float m = std::max(std::fabs(b.mn[a]), std::fabs(b.mx[a]));
+        float pad = std::isfinite(m) ? 4e-6f * std::max(m, 1e-3f) : 0.f;
+        if (b.mx[a] - b.mn[a] < 1e-4f) pad = std::max(pad, 1e-4f);
+        b.mn[a] -= pad;
+        b.mx[a] += pad;
+    }
+}
+
+void collect_leaves(const RtScene &sc, int id, bool flipped, std::vector<int> &leaves, std::vector<bool> &flips) {
+    const HostShape &s = sc.shapes[id];
+    if (s.kind == RT_KIND_CSG) {
+        for (size_t i = 0; i < s.children.size(); i++)
+            collect_leaves(sc, s.children[i], flipped != (s.op == RT_CSG_SUBTRACT && i > 0), leaves, flips);
+    } else {
+        leaves.push_back(id);
+        flips.push_back(flipped);
+    }
+}
+
+// inside(shape) for a given leaf-membership mask: the depth counting of
+// Impl/RenderableImpl.h:678-691 in closed form (union: any child; intersection: all
+// children; subtract: first child and none of the others).
+bool eval_csg(const RtScene &sc, int id, uint32_t mask, int &next_leaf) {
+    const HostShape &s = sc.shapes[id];
+    if (s.kind != RT_KIND_CSG) return (mask >> next_leaf++) & 1u;
+    int count = 0, depth = 0;
+    for (size_t i = 0; i < s.children.size(); i++) {
+        bool in = eval_csg(sc, s.children[i], mask, next_leaf);
+        count += in ? 1 : 0;
+        if (s.op == RT_CSG_SUBTRACT) depth += (i == 0) ? (in ? 1 : 0) : (in ? -1 : 0);
+    }
+    if (s.op == RT_CSG_UNION) return count >= 1;
+    if (s.op == RT_CSG_INTERSECTION) return count == (int)s.children.size();
+    return depth >= 1;
+}
+
+struct BuildItem { uint32_t ref; Box3 box; float c[3]; };
+
+struct Builder {
+    std::vector<BuildItem> items;
+    std::vector<float> nodes;      // 16 floats per node
+    uint32_t max_depth = 0;
+
+    static void put_box(float *dst, const Box3 &b) { for (int a = 0; a < 3; a++) { dst[a] = b.mn[a]; dst[3 + a] = b.mx[a]; } }
+
+    // Builds the subtree over items[lo, hi); returns its reference and box.
+    uint32_t build(size_t lo, size_t hi, Box3 &box, uint32_t depth) {
+        if (hi - lo == 1) {
+            box = items[lo].box;
+            return RT_REF_LEAF | items[lo].ref;
+        }
+        max_depth = std::max(max_depth, depth + 1);
+        Box3 all;
+        for (size_t i = lo; i < hi; i++) all.add(items[i].box);
+        float sx = all.mx[0] - all.mn[0], sy = all.mx[1] - all.mn[1], sz = all.mx[2] - all.mn[2];
+        int axis = sx > sy ? (sx > sz ? 0 : 2) : (sy > sz ? 1 : 2);         // AABB.swift:59-66
+        size_t mid = lo + (hi - lo + 1) / 2;                                  // Hittable.swift:620
+        // Only the split matters (each half is re-ordered on its own axis one level down),
+        // so a selection stands in for the reference's full sort.
+        std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
+                         [axis](const BuildItem &a, const BuildItem &b) { return a.c[axis] < b.c[axis]; });
+        uint32_t idx = (uint32_t)(nodes.size() / 16);
+        nodes.resize(nodes.size() + 16, 0.f);
+        Box3 lb, rb;
+        uint32_t l = build(lo, mid, lb, depth + 1);
+        uint32_t r = build(mid, hi, rb, depth + 1);
+        float *n = nodes.data() + 16 * (size_t)idx;
+        put_box(n, lb);
+        put_box(n + 6, rb);
+        memcpy(n + 12, &l, 4);
+        memcpy(n + 13, &r, 4);
+        box = all;
+        return idx;
+    }
+};
+
+int check_material(const RtScene *sc, size_t m) {
+    return m < sc->material_kinds.size() ? RT_OK : fail(RT_ERR_INVALID, "material_offset does not name a material added with rt_add_material");
+}
+
+int push_shape(RtScene *sc, HostShape &&s) {
+    if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
+    sc->shapes.push_back(std::move(s));
+    return (int)sc->shapes.size() - 1;
+}
+
+void set_xf(HostShape &s, const RtTransform &t) {
+    memcpy(s.rot, t.rotation, sizeof(s.rot));
+    memcpy(s.trans, t.translation, sizeof(s.trans));
+}
+
+hipStream_t as_stream(void *p) { return (hipStream_t)p; }
+
+// Shaders.metal:30-48, once per call instead of once per thread.
+void make_camera(const RtCameraConfig &c, int w, int h, RtDevCamera &out) {
+    auto sub = [](const float *a, const float *b, float *o) { for (int i = 0; i < 3; i++) o[i] = a[i] - b[i]; };
+    auto norm = [](float *v) { float l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); for (int i = 0; i < 3; i++) v[i] /= l; };
+    auto cross = [](const float *a, const float *b, float *o) {
+        o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    const float pi = 3.14159265358979323846f;
+    float half = c.vertical_FOV * pi / 360.f;
+    float vh = 2.f * std::tan(half) * c.focus_distance;
+    float vw = vh * (float)w / (float)h;
+    float wv[3], uv[3], vv[3];
+    sub(c.look_from, c.look_at, wv);
+    norm(wv);
+    cross(c.up, wv, uv);
+    norm(uv);
+    cross(wv, uv, vv);
+    float dr = c.focus_distance * std::tan(c.defocus_angle * pi / 360.f);
+    for (int i = 0; i < 3; i++) {
+        out.center[i] = c.look_from[i];
+        out.viewport_u[i] = vw * uv[i];
+        out.viewport_v[i] = -vh * vv[i];
+        out.viewport_center[i] = c.look_from[i] - c.focus_distance * wv[i];
+        out.defocus_u[i] = uv[i] * dr;
+        out.defocus_v[i] = vv[i] * dr;
+    }
+    out.inv_w = 1.f / (float)w;
+    out.inv_h = 1.f / (float)h;
+    out.defocus = c.defocus_angle > 0.f ? 1u : 0u;
+    out.background = c.background;
+}
+
+RtDevRender make_render(const RtRenderConfig &rc, int w, int h) {
+    RtDevRender r;
+    r.width = (uint32_t)w; r.height = (uint32_t)h;
+    r.spp = rc.samples_per_pixel; r.max_depth = rc.max_depth;
+    r.first_sample = rc.first_sample;
+    r.seed_lo = (uint32_t)rc.rng_seed; r.seed_hi = (uint32_t)(rc.rng_seed >> 32);
+    return r;
+}
+
+}  // namespace
+
+// ============================================================================ C ABI
+
+const char *rt_last_error(void) { return g_error.c_str(); }
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_context_create(int device_ordinal, RtContext **out) {
+    if (!out) return fail(RT_ERR_INVALID, "out is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail_hip(e, "hipGetDeviceCount");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(RT_ERR_INVALID, "no such device");
+    e = hipSetDevice(device_ordinal);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    RtContext *c = new RtContext();
+    c->device = device_ordinal;
+    (void)hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device_ordinal);
+    *out = c;
+    return RT_OK;
+}
+
+void rt_context_destroy(RtContext *c) { delete c; }
+
+int rt_scene_create(RtContext *ctx, RtScene **out) {
+    if (!ctx || !out) return fail(RT_ERR_INVALID, "null argument");
+    RtScene *s = new RtScene();
+    s->ctx = ctx;
+    *out = s;
+    return RT_OK;
+}
+
+void rt_scene_destroy(RtScene *s) { delete s; }
+
+int rt_add_material(RtScene *sc, const void *record, size_t size) {
+    if (!sc || !record || size < 4) return fail(RT_ERR_INVALID, "bad material record");
+    if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
+    uint32_t kind;
+    memcpy(&kind, record, 4);
+    float rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t tex = 0;
+    auto want = [&](size_t n) { return size == n ? RT_OK : fail(RT_ERR_INVALID, "material record size does not match its kind"); };
+    auto add_perlin = [&](const RtPerlinNoiseTexture &p) {
+        RtDevPerlin d;
+        memcpy(d.colors, p.colors, sizeof(d.colors));
+        d.frequency = p.frequency;
+        d.turbulence = p.turbulence;
+        memcpy(d.vectors, p.vectors, sizeof(d.vectors));
+        memcpy(d.permutations, p.permutations, sizeof(d.permutations));
+        sc->perlin.push_back(d);
+        return (uint32_t)sc->perlin.size() - 1;
+    };
+    switch (kind) {
+    case rt_material_kind_lambertian_colored:
+    case rt_material_kind_emissive_colored:
+    case rt_material_kind_isotropic_colored: {
+        if (want(sizeof(RtColoredLambertianMaterial)) < 0) return RT_ERR_INVALID;
+        const auto *m = (const RtColoredLambertianMaterial *)record;
+        rec[4] = m->albedo[0]; rec[5] = m->albedo[1]; rec[6] = m->albedo[2];
+        break;
+    }
+    case rt_material_kind_lambertian_textured: {
+        if (want(sizeof(RtTexturedLambertianMaterial)) < 0) return RT_ERR_INVALID;
+        tex = ((const RtTexturedLambertianMaterial *)record)->albedo.texture_id;
+        if (tex >= sc->textures.size()) return fail(RT_ERR_INVALID, "texture_id does not name a texture");
+        break;
+    }
+    case rt_material_kind_lambertian_perlin_noise:
+        if (want(sizeof(RtPerlinNoiseLambertianMaterial)) < 0) return RT_ERR_INVALID;
+        tex = add_perlin(((const RtPerlinNoiseLambertianMaterial *)record)->albedo);
+        break;
+    case rt_material_kind_metal_colored: {
+        if (want(sizeof(RtColoredMetalMaterial)) < 0) return RT_ERR_INVALID;
+        const auto *m = (const RtColoredMetalMaterial *)record;
+        rec[4] = m->albedo[0]; rec[5] = m->albedo[1]; rec[6] = m->albedo[2];
+        rec[2] = m->fuzz;
+        break;
+    }
+    case rt_material_kind_metal_textured: {
+        if (want(sizeof(RtTexturedMetalMaterial)) < 0) return RT_ERR_INVALID;
+        const auto *m = (const RtTexturedMetalMaterial *)record;
+        tex = m->albedo.texture_id;
+        if (tex >= sc->textures.size()) return fail(RT_ERR_INVALID, "texture_id does not name a texture");
+        rec[2] = m->fuzz;
+        break;
+    }
+    case rt_material_kind_metal_perlin_noise: {
+        if (want(sizeof(RtPerlinNoiseMetalMaterial)) < 0) return RT_ERR_INVALID;
+        const auto *m = (const RtPerlinNoiseMetalMaterial *)record;
+        tex = add_perlin(m->albedo);
+        rec[2] = m->fuzz;
+        break;
+    }
+    case rt_material_kind_dielectric:
+        if (want(sizeof(RtDielectricMaterial)) < 0) return RT_ERR_INVALID;
+        rec[3] = ((const RtDielectricMaterial *)record)->refraction_index;
+        break;
+    default:
+        return fail(RT_ERR_INVALID, "unknown material kind");
+    }
+    memcpy(&rec[0], &kind, 4);
+    memcpy(&rec[1], &tex, 4);
+    sc->materials.insert(sc->materials.end(), rec, rec + 8);
+    sc->material_kinds.push_back(kind);
+    return (int)sc->material_kinds.size() - 1;
+}
+
+int rt_add_texture_rgb8(RtScene *sc, int width, int height, const uint8_t *rgb) {
+    if (!sc || !rgb || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "bad texture");
+    if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
+    HostTexture t;
+    t.w = width; t.h = height;
+    t.rgba.resize((size_t)width * height);
+    for (size_t i = 0; i < t.rgba.size(); i++)
+        t.rgba[i] = (uint32_t)rgb[3 * i] | ((uint32_t)rgb[3 * i + 1] << 8) | ((uint32_t)rgb[3 * i + 2] << 16) | 0xFF000000u;
+    sc->textures.push_back(std::move(t));
+    return (int)sc->textures.size() - 1;
+}
+
+int rt_shape_sphere(RtScene *sc, const RtSphere *p) {
+    if (!sc || !p) return fail(RT_ERR_INVALID, "null argument");
+    if (!(p->radius > 0.f)) return fail(RT_ERR_INVALID, "sphere radius must be positive");
+    if (check_material(sc, p->material_offset) < 0) return RT_ERR_INVALID;
+    HostShape s;
+    s.kind = RT_KIND_SPHERE;
+    set_xf(s, p->transform);
+    s.radius = p->radius;
+    s.mat[0] = (uint32_t)p->material_offset;
+    return push_shape(sc, std::move(s));
+}
+
+int rt_shape_cylinder(RtScene *sc, const RtCylinder *p) {
+    if (!sc || !p) return fail(RT_ERR_INVALID, "null argument");
+    if (!(p->radius >= 0.f) || !(p->height >= 0.f)) return fail(RT_ERR_INVALID, "cylinder radius/height must not be negative");
+    if (check_material(sc, p->bottom_material_offset) < 0 || check_material(sc, p->top_material_offset) < 0 ||
+        check_material(sc, p->side_material_offset) < 0)
+        return RT_ERR_INVALID;
+    HostShape s;
+    s.kind = RT_KIND_CYLINDER;
+    set_xf(s, p->transform);
+    s.radius = p->radius; s.height = p->height;
+    s.mat[0] = (uint32_t)p->bottom_material_offset;
+    s.mat[1] = (uint32_t)p->top_material_offset;
+    s.mat[2] = (uint32_t)p->side_material_offset;
+    return push_shape(sc, std::move(s));
+}
+
+int rt_shape_cuboid(RtScene *sc, const RtCuboid *p) {
+    if (!sc || !p) return fail(RT_ERR_INVALID, "null argument");
+    HostShape s;
+    s.kind = RT_KIND_CUBOID;
+    set_xf(s, p->transform);
+    for (int i = 0; i < 3; i++) s.size[i] = p->size[i];
+    for (int i = 0; i < 6; i++) {
+        if (check_material(sc, p->material_offset[i]) < 0) return RT_ERR_INVALID;
+        s.mat[i] = (uint32_t)p->material_offset[i];
+    }
+    return push_shape(sc, std::move(s));
+}
+
+int rt_shape_quad(RtScene *sc, const RtQuad *p) {
+    if (!sc || !p) return fail(RT_ERR_INVALID, "null argument");
+    if (check_material(sc, p->material_offset) < 0) return RT_ERR_INVALID;
+    HostShape s;
+    s.kind = RT_KIND_QUAD;
+    memcpy(s.quad + 0, p->origin, 12);
+    memcpy(s.quad + 3, p->u, 12);
+    memcpy(s.quad + 6, p->v, 12);
+    memcpy(s.quad + 9, p->w, 12);
+    memcpy(s.quad + 12, p->normal, 12);
+    s.quad[15] = p->d;
+    s.mat[0] = (uint32_t)p->material_offset;
+    return push_shape(sc, std::move(s));
+}
+
+int rt_shape_csg(RtScene *sc, int op, int n_children, const int *children) {
+    if (!sc || !children || n_children < 1) return fail(RT_ERR_INVALID, "a CSG shape needs children");
+    if (op < RT_CSG_UNION || op > RT_CSG_SUBTRACT) return fail(RT_ERR_INVALID, "unknown CSG operation");
+    if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
+    HostShape s;
+    s.kind = RT_KIND_CSG;
+    s.op = op;
+    for (int i = 0; i < n_children; i++) {
+        int c = children[i];
+        if (c < 0 || c >= (int)sc->shapes.size()) return fail(RT_ERR_INVALID, "bad child shape id");
+        if (sc->shapes[c].kind == RT_KIND_CDV)
+            return fail(RT_ERR_INVALID, "a constant-density volume cannot be a CSG operand (the reference's Composition "
+                                        "builds its children without a generator, RenderableImpl.h:645-654)");
+        if (sc->shapes[c].parent >= 0 || sc->shapes[c].object >= 0) return fail(RT_ERR_INVALID, "shape is already in use");
+        s.children.push_back(c);
+    }
+    int id = (int)sc->shapes.size();
+    std::vector<int> leaves;
+    std::vector<bool> flips;
+    sc->shapes.push_back(s);
+    collect_leaves(*sc, id, false, leaves, flips);
+    if (leaves.size() > RT_CSG_MAX_LEAVES) {
+        sc->shapes.pop_back();
+        return fail(RT_ERR_LIMIT, "more than RT_CSG_MAX_LEAVES primitives under one CSG shape");
+    }
+    for (int c : s.children) sc->shapes[c].parent = id;
+    return id;
+}
+
+int rt_shape_cdv(RtScene *sc, int base, float density) {
+    if (!sc || base < 0 || base >= (int)sc->shapes.size()) return fail(RT_ERR_INVALID, "bad base shape id");
+    if (!(density > 0.f)) return fail(RT_ERR_INVALID, "density must be positive");
+    if (sc->shapes[base].kind == RT_KIND_CDV) return fail(RT_ERR_INVALID, "a volume cannot wrap a volume");
+    if (sc->shapes[base].parent >= 0 || sc->shapes[base].object >= 0) return fail(RT_ERR_INVALID, "shape is already in use");
+    HostShape s;
+    s.kind = RT_KIND_CDV;
+    s.base = base;
+    s.density = density;
+    int id = push_shape(sc, std::move(s));
+    if (id >= 0) sc->shapes[base].parent = id;
+    return id;
+}
+
+int rt_add_object(RtScene *sc, int shape) {
+    if (!sc || shape < 0 || shape >= (int)sc->shapes.size()) return fail(RT_ERR_INVALID, "bad shape id");
+    if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
+    if (sc->shapes[shape].parent >= 0 || sc->shapes[shape].object >= 0) return fail(RT_ERR_INVALID, "shape is already in use");
+    if (!sc->bulk_spheres.empty()) return fail(RT_ERR_STATE, "rt_add_sphere_objects must be the last objects added");
+    sc->objects.push_back(shape);
+    sc->shapes[shape].object = (int)sc->objects.size() - 1;
+    return sc->shapes[shape].object;
+}
+
+int rt_add_sphere_objects(RtScene *sc, int n, const float *center_radius, const uint32_t *material_offsets) {
+    if (!sc || n < 0 || (n > 0 && (!center_radius || !material_offsets))) return fail(RT_ERR_INVALID, "bad argument");
+    if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
+    for (int i = 0; i < n; i++) {
+        if (check_material(sc, material_offsets[i]) < 0) return RT_ERR_INVALID;
+        if (!(center_radius[4 * (size_t)i + 3] > 0.f)) return fail(RT_ERR_INVALID, "sphere radius must be positive");
+    }
+    int first = (int)sc->objects.size() + (int)sc->bulk_mats.size();
+    sc->bulk_spheres.insert(sc->bulk_spheres.end(), center_radius, center_radius + 4 * (size_t)n);
+    sc->bulk_mats.insert(sc->bulk_mats.end(), material_offsets, material_offsets + n);
+    return first;
+}
+
+int rt_scene_commit(RtScene *sc) {
+    if (!sc) return fail(RT_ERR_INVALID, "null scene");
+    if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
+    hipError_t he = hipSetDevice(sc->ctx->device);
+    if (he != hipSuccess) return fail_hip(he, "hipSetDevice");
+    sc->stats = RtSceneStats{};
+
+    // ---- device slots for every shape (objects or not: rt_intervals may ask for any)
+    std::vector<float> spheres, sphere_rot, xprims;
+    std::vector<uint32_t> sphere_mat, sphere_obj, xprim_mat, xprim_obj, csg_obj, cdv_obj;
+    std::vector<RtDevCsg> csg;
+    std::vector<RtDevCdv> cdv;
+    bool any_rot = false;
+    auto owner_object = [&](int id) {
+        int cur = id;
+        while (sc->shapes[cur].parent >= 0) cur = sc->shapes[cur].parent;
+        return sc->shapes[cur].object >= 0 ? (uint32_t)sc->shapes[cur].object : 0u;
+    };
+    for (size_t id = 0; id < sc->shapes.size(); id++) {
+        HostShape &s = sc->shapes[id];
+        uint32_t obj = owner_object((int)id);
+        if (s.kind == RT_KIND_SPHERE) {
+            s.ref = rt_make_ref(RT_KIND_SPHERE, (uint32_t)(spheres.size() / 4));
+            spheres.insert(spheres.end(), {s.trans[0], s.trans[1], s.trans[2], s.radius});
+            const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            if (memcmp(s.rot, ident, sizeof(ident)) != 0) any_rot = true;
+            // rows of transpose(R) = columns of R, padded to float4
+            for (int c = 0; c < 3; c++) sphere_rot.insert(sphere_rot.end(), {s.rot[3 * c], s.rot[3 * c + 1], s.rot[3 * c + 2], 0.f});
+            sphere_mat.push_back(s.mat[0]);
+            sphere_obj.push_back(obj);
+        } else if (s.kind <= RT_KIND_QUAD) {
+            s.ref = rt_make_ref(s.kind, (uint32_t)(xprims.size() / 16));
+            float rec[16] = {0};
+            if (s.kind == RT_KIND_QUAD) {
+                memcpy(rec, s.quad, sizeof(rec));
+            } else {
+                memcpy(rec, s.rot, 36);
+                memcpy(rec + 9, s.trans, 12);
+                if (s.kind == RT_KIND_CYLINDER) { rec[12] = s.radius; rec[13] = s.height; }
+                else { rec[12] = s.size[0]; rec[13] = s.size[1]; rec[14] = s.size[2]; }
+            }
+            xprims.insert(xprims.end(), rec, rec + 16);
+            xprim_mat.insert(xprim_mat.end(), s.mat, s.mat + 6);
+            xprim_obj.push_back(obj);
+        }
+    }
+    for (size_t id = 0; id < sc->shapes.size(); id++) {
+        HostShape &s = sc->shapes[id];
+        if (s.kind != RT_KIND_CSG) continue;
+        std::vector<int> leaves;
+        std::vector<bool> flips;
+        collect_leaves(*sc, (int)id, false, leaves, flips);
+        RtDevCsg rec;
+        memset(&rec, 0, sizeof(rec));
+        rec.n_leaves = (uint32_t)leaves.size();
+        for (size_t i = 0; i < leaves.size(); i++) {
+            rec.leaf[i] = sc->shapes[leaves[i]].ref;
+            if (flips[i]) rec.flip_mask |= 1u << i;
+        }
+        for (uint32_t mask = 0; mask < (1u << leaves.size()); mask++) {
+            int next = 0;
+            if (eval_csg(*sc, (int)id, mask, next)) rec.truth[mask >> 5] |= 1u << (mask & 31u);
+        }
+        s.ref = rt_make_ref(RT_KIND_CSG, (uint32_t)csg.size());
+        csg.push_back(rec);
+        csg_obj.push_back(owner_object((int)id));
+    }
+    for (size_t id = 0; id < sc->shapes.size(); id++) {
+        HostShape &s = sc->shapes[id];
+        if (s.kind != RT_KIND_CDV) continue;
+        RtDevCdv rec;
+        rec.base = sc->shapes[s.base].ref;
+        rec.neg_inv_density = -1.f / s.density;
+        s.ref = rt_make_ref(RT_KIND_CDV, (uint32_t)cdv.size());
+        cdv.push_back(rec);
+        cdv_obj.push_back(owner_object((int)id));
+    }
+    // bulk spheres come after the described ones
+    uint32_t first_bulk_object = (uint32_t)sc->objects.size();
+    uint32_t first_bulk_sphere = (uint32_t)(spheres.size() / 4);
+    size_t n_bulk = sc->bulk_mats.size();
+    if (n_bulk) {
+        spheres.insert(spheres.end(), sc->bulk_spheres.begin(), sc->bulk_spheres.end());
+        sphere_mat.insert(sphere_mat.end(), sc->bulk_mats.begin(), sc->bulk_mats.end());
+        for (size_t i = 0; i < n_bulk; i++) sphere_obj.push_back(first_bulk_object + (uint32_t)i);
+        if (any_rot) sphere_rot.resize(spheres.size() * 3, 0.f);
+        if (any_rot)
+            for (size_t i = first_bulk_sphere; i < spheres.size() / 4; i++) {
+                float *r = sphere_rot.data() + 12 * i;
+                r[0] = 1; r[5] = 1; r[10] = 1;
+            }
+    }
+    if (spheres.size() / 4 > RT_INDEX_MASK || xprims.size() / 16 > RT_INDEX_MASK)
+        return fail(RT_ERR_LIMIT, "too many primitives");
+
+    // ---- BVH over the objects
+    Builder bld;
+    bld.items.reserve(sc->objects.size() + n_bulk);
+    uint32_t feat = 0;
+    for (size_t o = 0; o < sc->objects.size(); o++) {
+        const HostShape &s = sc->shapes[sc->objects[o]];
+        BuildItem it;
+        it.ref = s.ref;
+        it.box = shape_box(*sc, sc->objects[o]);
+        pad_box(it.box);
+        if (s.kind != RT_KIND_SPHERE) feat |= RT_FEAT_XPRIM;
+        bld.items.push_back(it);
+    }
+    for (size_t i = 0; i < n_bulk; i++) {
+        const float *g = sc->bulk_spheres.data() + 4 * i;
+        BuildItem it;
+        it.ref = rt_make_ref(RT_KIND_SPHERE, first_bulk_sphere + (uint32_t)i);
+        for (int a = 0; a < 3; a++) { it.box.mn[a] = g[a] - g[3]; it.box.mx[a] = g[a] + g[3]; }
+        pad_box(it.box);
+        bld.items.push_back(it);
+    }
+    for (auto &it : bld.items)
+        for (int a = 0; a < 3; a++) {
+            float c = 0.5f * (it.box.mn[a] + it.box.mx[a]);
+            it.c[a] = std::isfinite(c) ? c : 0.f;
+        }
+    for (uint32_t k : sc->material_kinds)
+        if (k == 2 || k == 3 || k == 5 || k == 6) feat |= RT_FEAT_TEXTURE;
+
+    uint32_t root = RT_REF_NONE;
+    if (bld.items.size() == 1) {
+        // a single object: one node whose right child is absent
+        bld.nodes.assign(16, 0.f);
+        Builder::put_box(bld.nodes.data(), bld.items[0].box);
+        Box3 none;
+        Builder::put_box(bld.nodes.data() + 6, none);
+        uint32_t l = RT_REF_LEAF | bld.items[0].ref, r = RT_REF_NONE;
+        memcpy(bld.nodes.data() + 12, &l, 4);
+        memcpy(bld.nodes.data() + 13, &r, 4);
+        root = 0;
+        bld.max_depth = 1;
+    } else if (bld.items.size() > 1) {
+        Box3 all;
+        root = bld.build(0, bld.items.size(), all, 0);
+    }
+    if (bld.max_depth > RT_STACK_DEPTH) return fail(RT_ERR_LIMIT, "BVH deeper than the traversal stack");
+
+    // ---- textures
+    std::vector<RtDevTexture> tex_desc;
+    std::vector<uint32_t> texels;
+    for (const HostTexture &t : sc->textures) {
+        RtDevTexture d;
+        d.offset = (uint32_t)texels.size();
+        d.width = (uint32_t)t.w; d.height = (uint32_t)t.h; d.pad = 0;
+        tex_desc.push_back(d);
+        texels.insert(texels.end(), t.rgba.begin(), t.rgba.end());
+    }
+
+    // ---- upload
+    RtDevScene &d = sc->dev;
+    memset(&d, 0, sizeof(d));
+    if (!any_rot) sphere_rot.clear();
+    int rc = RT_OK;
+    if ((rc = upload(sc, bld.nodes, &d.nodes)) < 0) return rc;
+    if ((rc = upload(sc, spheres, &d.spheres)) < 0) return rc;
+    if ((rc = upload(sc, sphere_rot, &d.sphere_rot)) < 0) return rc;
+    if ((rc = upload(sc, sphere_mat, &d.sphere_mat)) < 0) return rc;
+    if ((rc = upload(sc, sphere_obj, &d.sphere_obj)) < 0) return rc;
+    if ((rc = upload(sc, xprims, &d.xprims)) < 0) return rc;
+    if ((rc = upload(sc, xprim_mat, &d.xprim_mat)) < 0) return rc;
+    if ((rc = upload(sc, xprim_obj, &d.xprim_obj)) < 0) return rc;
+    if ((rc = upload(sc, csg, &d.csg)) < 0) return rc;
+    if ((rc = upload(sc, csg_obj, &d.csg_obj)) < 0) return rc;
+    if ((rc = upload(sc, cdv, &d.cdv)) < 0) return rc;
+    if ((rc = upload(sc, cdv_obj, &d.cdv_obj)) < 0) return rc;
+    if ((rc = upload(sc, sc->materials, &d.materials)) < 0) return rc;
+    if ((rc = upload(sc, tex_desc, &d.textures)) < 0) return rc;
+    if ((rc = upload(sc, texels, &d.texels)) < 0) return rc;
+    if ((rc = upload(sc, sc->perlin, &d.perlin)) < 0) return rc;
+    d.root = root;
+    d.n_nodes = (uint32_t)(bld.nodes.size() / 16);
+    sc->feat = feat;
+
+    RtSceneStats &st = sc->stats;
+    st.n_objects = (uint32_t)bld.items.size();
+    st.n_nodes = d.n_nodes;
+    st.bvh_depth = bld.max_depth;
+    st.n_spheres = (uint32_t)(spheres.size() / 4);
+    for (const HostShape &s : sc->shapes) {
+        if (s.kind == RT_KIND_CYLINDER) st.n_cylinders++;
+        if (s.kind == RT_KIND_CUBOID) st.n_cuboids++;
+        if (s.kind == RT_KIND_QUAD) st.n_quads++;
+    }
+    st.n_csg = (uint32_t)csg.size();
+    st.n_cdv = (uint32_t)cdv.size();
+    st.n_materials = (uint32_t)sc->material_kinds.size();
+    st.n_textures = (uint32_t)sc->textures.size();
+    st.n_perlin = (uint32_t)sc->perlin.size();
+    sc->committed = true;
+    return RT_OK;
+}
+
+int rt_scene_stats(const RtScene *sc, RtSceneStats *out) {
+    if (!sc || !out) return fail(RT_ERR_INVALID, "null argument");
+    if (!sc->committed) return fail(RT_ERR_STATE, "scene not committed");
+    *out = sc->stats;
+    return RT_OK;
+}
+
+int rt_first_hit(RtScene *sc, const float *rays_dev, int n, float tmin, float tmax, uint64_t volume_key, RtHit *out_dev,
+                 void *stream) {
+    if (!sc || n < 0 || (n > 0 && (!rays_dev || !out_dev))) return fail(RT_ERR_INVALID, "bad argument");
+    if (!sc->committed) return fail(RT_ERR_STATE, "scene not committed");
+    hipError_t e = rt_launch_first_hit(sc->dev, sc->feat, rays_dev, n, tmin, tmax, volume_key, out_dev, as_stream(stream));
+    return e == hipSuccess ? RT_OK : fail_hip(e, "first-hit launch");
+}
+
+int rt_intervals(RtScene *sc, int shape, const float *rays_dev, int n, const float *scripted_u_dev, int n_scripted,
+                 uint64_t volume_key, RtEvent *events_dev, int32_t *counts_dev, void *stream) {
+    if (!sc || n < 0 || (n > 0 && (!rays_dev || !events_dev || !counts_dev))) return fail(RT_ERR_INVALID, "bad argument");
+    if (!sc->committed) return fail(RT_ERR_STATE, "scene not committed");
+    if (shape < 0 || shape >= (int)sc->shapes.size()) return fail(RT_ERR_INVALID, "bad shape id");
+    if (scripted_u_dev && n_scripted <= 0) return fail(RT_ERR_INVALID, "scripted values given but n_scripted <= 0");
+    const HostShape &s = sc->shapes[shape];
+    uint32_t object = s.object >= 0 ? (uint32_t)s.object : 0u;
+    hipError_t e = rt_launch_intervals(sc->dev, s.ref, rays_dev, n, scripted_u_dev, n_scripted, volume_key, object,
+                                       events_dev, counts_dev, as_stream(stream));
+    return e == hipSuccess ? RT_OK : fail_hip(e, "intervals launch");
+}
+
+int rt_camera_rays(RtContext *ctx, const RtCameraConfig *cc, const RtRenderConfig *rc, int width, int height, int x0,
+                   int y0, int w, int h, float *rays_out_dev, void *stream) {
+    if (!ctx || !cc || !rc || !rays_out_dev || width <= 0 || height <= 0 || w < 0 || h < 0)
+        return fail(RT_ERR_INVALID, "bad argument");
+    RtDevCamera cam;
+    make_camera(*cc, width, height, cam);
+    RtDevRender r = make_render(*rc, width, height);
+    hipError_t e = rt_launch_camera_rays(cam, r, x0, y0, w, h, rays_out_dev, as_stream(stream));
+    return e == hipSuccess ? RT_OK : fail_hip(e, "camera-rays launch");
+}
+
+size_t rt_render_workspace_size(int pipeline, int width, int height) {
+    if (width <= 0 || height <= 0) return 0;
+    if (pipeline == RT_PIPELINE_FUSED) return RT_FUSED_WORKSPACE;
+    return rt_wavefront_bytes((uint32_t)width * (uint32_t)height * RT_WAVEFRONT_BATCH_SPP);
+}
+
+int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, int pipeline, int width, int height,
+              float *accum_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
+    if (!sc || !cc || !rc || !accum_dev || !workspace_dev || width <= 0 || height <= 0)
+        return fail(RT_ERR_INVALID, "bad argument");
+    if (!sc->committed) return fail(RT_ERR_STATE, "scene not committed");
+    if ((uint64_t)width * (uint64_t)height > (1u << 28)) return fail(RT_ERR_LIMIT, "image too large");
+    RtDevCamera cam;
+    make_camera(*cc, width, height, cam);
+    RtDevRender r = make_render(*rc, width, height);
+    hipError_t e;
+    if (pipeline == RT_PIPELINE_FUSED) {
+        if (workspace_bytes < RT_FUSED_WORKSPACE) return fail(RT_ERR_INVALID, "workspace too small");
+        e = rt_render_fused(sc->dev, sc->feat, cam, r, accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);
+    } else if (pipeline == RT_PIPELINE_WAVEFRONT) {
+        if (workspace_bytes < rt_wavefront_bytes((uint32_t)width * (uint32_t)height))
+            return fail(RT_ERR_INVALID, "workspace too small");
+        e = rt_render_wavefront(sc->dev, sc->feat, cam, r, accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);
+    } else {
+        return fail(RT_ERR_INVALID, "unknown pipeline");
+    }
+    return e == hipSuccess ? RT_OK : fail_hip(e, "render");
+}
+
+int rt_resolve_rgb8(RtContext *ctx, const float *accum_dev, uint32_t n_samples, int width, int height,
+                    uint8_t *rgbx_out_dev, void *stream) {
+    if (!ctx || !accum_dev || !rgbx_out_dev || width <= 0 || height <= 0 || n_samples == 0)
+        return fail(RT_ERR_INVALID, "bad argument");
+    hipError_t e = rt_launch_resolve(accum_dev, 1.f / (float)n_samples, width, height, rgbx_out_dev, as_stream(stream));
+    return e == hipSuccess ? RT_OK : fail_hip(e, "resolve launch");
+}
+
+int rt_kernel_time(RtScene *sc, int reset, double *total_ms, uint64_t *launches, const char **kernel_name) {
+    if (!sc) return fail(RT_ERR_INVALID, "null scene");
+    sc->timer.collect();
+    if (total_ms) *total_ms = sc->timer.total_ms;
+    if (launches) *launches = sc->timer.launches;
+    if (kernel_name) *kernel_name = sc->timer.name;
+    if (reset) sc->timer.reset();
+    return RT_OK;
+}

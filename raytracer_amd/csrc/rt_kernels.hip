@@ -1,0 +1,577 @@
+// rt_kernels.hip - HIP kernels of the path-tracing hot path (gfx950 / MI355X) and their
+// launchers.
+//
+// Two forms of the render loop (Shaders.metal:93-159 is the reference's single kernel):
+//
+//  * wavefront: k_wf_raygen -> { k_wf_extend -> k_wf_shade } x max_depth -> k_wf_accumulate.
+//    Path state is SoA float4 streams in HBM (80 B per path).  Shade compacts the
+//    surviving paths into the other queue with one ballot + one atomic per wave, so every
+//    extend launch runs on dense waves.  Finished samples are written to a per-sample
+//    slot and summed per pixel by the accumulate kernel: no scattered float atomics.
+//
+//  * fused: k_fused, one persistent kernel.  A wave owns an 8x8 pixel tile for a chunk of
+//    samples and runs raygen / extend / shade as wave-wide phases; a lane whose path ended
+//    takes the tile's next (pixel, sample) at once, so lanes stay busy while path state
+//    never leaves registers.  Tile sums are kept in LDS and flushed once per work item.
+//
+// Both draw sample s of pixel (x, y) from the same generator stream, so they are the same
+// estimator sample for sample.
+#include "rt_device.h"
+#include "rt_launch.h"
+
+#define RT_T_MIN 1e-3f          // Camera.swift:117
+#define RT_WAVES (RT_BLOCK / 64)
+
+RT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+RT_DEV uint32_t prefix_rank(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// ------------------------------------------------------------------ parity surface
+template <int FEAT>
+__global__ __launch_bounds__(RT_BLOCK) void k_first_hit(RtDevScene s, const float *rays, int n, float tmin, float tmax,
+                                                         uint64_t volume_key, RtHit *out) {
+    __shared__ uint32_t stack[RT_STACK_DEPTH * RT_BLOCK];
+    int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float *r = rays + 6 * (size_t)i;
+    f3 o = mk3(r[0], r[1], r[2]), d = mk3(r[3], r[4], r[5]);
+    Best b;
+    bool found = trace<!(FEAT & RT_FEAT_XPRIM)>(s, o, d, tmin, tmax, volume_key, nullptr, 0, stack + threadIdx.x, b);
+    RtHit h;
+    h.t = 0.f;
+    h.point[0] = h.point[1] = h.point[2] = 0.f;
+    h.normal[0] = h.normal[1] = h.normal[2] = 0.f;
+    h.uv[0] = h.uv[1] = 0.f;
+    h.object = -1;
+    h.material_offset = 0;
+    h.front_face = 0;
+    if (found) {
+        HitRecord hr;
+        complete_hit(s, b, o, d, true, hr);
+        h.t = b.t;
+        h.point[0] = hr.point.x; h.point[1] = hr.point.y; h.point[2] = hr.point.z;
+        h.normal[0] = hr.normal.x; h.normal[1] = hr.normal.y; h.normal[2] = hr.normal.z;
+        h.uv[0] = hr.u; h.uv[1] = hr.v;
+        h.object = (int32_t)hr.object;
+        h.material_offset = hr.material;
+        h.front_face = hr.front ? 1 : 0;
+    }
+    out[i] = h;
+}
+
+RT_DEV void put_event(RtEvent *ev, int32_t &n, float t, bool is_exit, const Surface *sf, f3 o, f3 d) {
+    if (n >= RT_MAX_EVENTS) return;
+    RtEvent e;
+    e.t = t;
+    e.is_exit = is_exit ? 1 : 0;
+    e.pad = 0;
+    e.point[0] = e.point[1] = e.point[2] = 0.f;
+    e.normal[0] = e.normal[1] = e.normal[2] = 0.f;
+    e.uv[0] = e.uv[1] = 0.f;
+    e.material_offset = 0;
+    if (sf && finite(t)) {
+        f3 p = madd(d, t, o);
+        e.point[0] = p.x; e.point[1] = p.y; e.point[2] = p.z;
+        e.normal[0] = sf->normal.x; e.normal[1] = sf->normal.y; e.normal[2] = sf->normal.z;
+        e.uv[0] = sf->u; e.uv[1] = sf->v;
+        e.material_offset = sf->material;
+    }
+    ev[n++] = e;
+}
+
+// All boundary crossings of one shape, in order: the enumerator protocol of
+// Impl/RenderableImpl.h as a list.
+__global__ __launch_bounds__(RT_BLOCK) void k_intervals(RtDevScene s, uint32_t ref, const float *rays, int n,
+                                                         const float *scripted, int n_scripted, uint64_t volume_key,
+                                                         uint32_t object, RtEvent *events, int32_t *counts) {
+    int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float *r = rays + 6 * (size_t)i;
+    f3 o = mk3(r[0], r[1], r[2]), d = mk3(r[3], r[4], r[5]);
+    RtEvent *ev = events + (size_t)i * RT_MAX_EVENTS;
+    int32_t cnt = 0;
+    uint32_t kind = (ref >> RT_KIND_SHIFT) & 7u, idx = ref & RT_INDEX_MASK;
+    if (kind <= RT_KIND_QUAD) {
+        Span sp = prim_span(s, ref, o, d);
+        if (span_valid(sp)) {
+            Surface a, b;
+            if (finite(sp.t0)) a = prim_surface(s, ref, sp.tag0, o, d, sp.t0, true);
+            if (finite(sp.t1)) b = prim_surface(s, ref, sp.tag1, o, d, sp.t1, true);
+            put_event(ev, cnt, sp.t0, false, &a, o, d);
+            put_event(ev, cnt, sp.t1, true, &b, o, d);
+        }
+    } else if (kind == RT_KIND_CSG) {
+        CsgIter it;
+        csg_begin(s, idx, o, d, it);
+        while (csg_next(it)) {
+            uint32_t code = it.tag | (it.leaf << 3);
+            Surface sf;
+            if (finite(it.t)) sf = csg_surface(s, idx, code, o, d, it.t, true);
+            put_event(ev, cnt, it.t, it.is_exit, &sf, o, d);
+        }
+    } else {
+        // ConstantDensityVolume<Impl>::HitEnumerator, RenderableImpl.h:727-802
+        const RtDevCdv cv = s.cdv[idx];
+        Pcg vr = pcg_seed(volume_key, (uint64_t)(object + 1u));
+        uint32_t draw = 0;
+        uint32_t bkind = (cv.base >> RT_KIND_SHIFT) & 7u, bidx = cv.base & RT_INDEX_MASK;
+        CsgIter it;
+        Span sp = empty_span();
+        bool prim_pending = false;
+        if (bkind == RT_KIND_CSG) csg_begin(s, bidx, o, d, it);
+        else { sp = prim_span(s, cv.base, o, d); prim_pending = span_valid(sp); }
+        while (true) {
+            float t_entry, t_exit = RT_INF;
+            uint32_t entry_code, exit_code = 0;
+            bool has_exit;
+            if (bkind == RT_KIND_CSG) {
+                if (!csg_next(it)) break;
+                t_entry = it.t; entry_code = it.tag | (it.leaf << 3);
+                has_exit = csg_next(it);
+                if (has_exit) { t_exit = it.t; exit_code = it.tag | (it.leaf << 3); }
+            } else {
+                if (!prim_pending) break;
+                prim_pending = false;
+                t_entry = sp.t0; entry_code = sp.tag0;
+                has_exit = true; t_exit = sp.t1; exit_code = sp.tag1;
+            }
+            float t1 = fmaxf(0.f, t_entry);
+            if (t1 < t_exit) {
+                float u = scripted ? scripted[draw % (uint32_t)n_scripted] : rnd(vr);
+                draw++;
+                float t = fmaf(logf(1.f - u), cv.neg_inv_density, t1);
+                if (t <= t_exit) {
+                    Surface en = bkind == RT_KIND_CSG ? csg_surface(s, bidx, entry_code, o, d, t_entry, true)
+                                                      : prim_surface(s, cv.base, entry_code, o, d, t_entry, true);
+                    en.normal = -d;
+                    put_event(ev, cnt, t, false, &en, o, d);
+                    if (has_exit) {
+                        Surface ex;
+                        if (finite(t_exit))
+                            ex = bkind == RT_KIND_CSG ? csg_surface(s, bidx, exit_code, o, d, t_exit, true)
+                                                      : prim_surface(s, cv.base, exit_code, o, d, t_exit, true);
+                        put_event(ev, cnt, t_exit, true, &ex, o, d);
+                    }
+                }
+            }
+            if (!has_exit) break;
+        }
+    }
+    counts[i] = cnt;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_camera_rays(RtDevCamera cam, RtDevRender rc, int x0, int y0, int w, int h,
+                                                           float *out) {
+    uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    uint32_t total = (uint32_t)w * (uint32_t)h * rc.spp;
+    if (i >= total) return;
+    uint32_t pix = i / rc.spp, sidx = i % rc.spp;
+    uint32_t x = (uint32_t)x0 + pix % (uint32_t)w, y = (uint32_t)y0 + pix / (uint32_t)w;
+    uint64_t seed = ((uint64_t)rc.seed_hi << 32) | rc.seed_lo;
+    Pcg g = sample_stream(seed, rc.first_sample + sidx, x, y);
+    f3 o, d;
+    camera_ray(cam, x, y, g, o, d);
+    float *r = out + 6 * (size_t)i;
+    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
+}
+
+// Camera.swift:92, Vector3D.swift:185-191,208-211: mean, gamma 2, quantise.
+__global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float *accum, float inv_samples, int npix, uint8_t *rgbx) {
+    int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= npix) return;
+    uint32_t px = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float v = fminf(fsqrt(fmaxf(accum[3 * (size_t)i + c] * inv_samples, 0.f)), 1.f);
+        uint32_t q = (uint32_t)floorf(255.99998f * v);
+        px |= (q > 255u ? 255u : q) << (8 * c);
+    }
+    ((uint32_t *)rgbx)[i] = px;
+}
+
+// ------------------------------------------------------------------ one bounce of shading
+// Shaders.metal:102-119 for one path: adds emission / background, scatters, and says
+// whether the path goes on.  Depth exhaustion keeps what was gathered so far
+// (Camera.swift:114-122) instead of zeroing it (Shaders.metal:127-128).
+template <int FEAT>
+RT_DEV bool shade_path(const RtDevScene &s, uint32_t background, uint32_t max_depth, bool found, const Best &b,
+                       f3 &o, f3 &d, f3 &thr, f3 &rad, uint32_t &depth, Pcg &g) {
+    if (!found) {
+        rad = rad + thr * background_color(background, d);
+        return false;
+    }
+    HitRecord h;
+    uint32_t kind = (b.ref >> RT_KIND_SHIFT) & 7u;
+    bool maybe_uv = (FEAT & RT_FEAT_TEXTURE) != 0;
+    if (!(FEAT & RT_FEAT_XPRIM)) {
+        // spheres only: skip the generic completion
+        uint32_t idx = b.ref & RT_INDEX_MASK;
+        Surface sf = prim_surface(s, b.ref, 0, o, d, b.t, false);
+        h.point = madd(d, b.t, o);
+        h.material = sf.material;
+        h.u = h.v = 0.f;
+        if (dot(sf.normal, d) > 0.f) { h.normal = -sf.normal; h.front = false; } else { h.normal = sf.normal; h.front = true; }
+        (void)idx; (void)kind;
+        if (maybe_uv) {
+            Material mm = load_material(s, h.material);
+            if (material_wants_uv(mm.kind)) {
+                sf = prim_surface(s, b.ref, 0, o, d, b.t, true);
+                h.u = sf.u; h.v = sf.v;
+            }
+        }
+    } else {
+        complete_hit(s, b, o, d, maybe_uv, h);
+    }
+    Material m = load_material(s, h.material);
+    f3 emitted, atten, nd;
+    bool did = scatter(s, m, d, h, g, emitted, atten, nd);
+    rad = rad + thr * emitted;
+    if (!did) return false;
+    thr = thr * atten;
+    o = h.point;
+    d = nd;
+    depth++;
+    return depth < max_depth;
+}
+
+// ------------------------------------------------------------------ wavefront pipeline
+struct WfQueues {
+    float4 *ray_o[2], *ray_d[2], *thr[2], *rad[2];
+    uint4 *rng[2];
+    float4 *hit, *sample_rad;
+    uint32_t *counts;
+};
+
+// Ray generation: path i of the batch is sample i / npix of pixel i % npix.
+__global__ __launch_bounds__(RT_BLOCK) void k_wf_raygen(WfQueues q, RtDevCamera cam, RtDevRender rc, uint32_t batch_spp) {
+    uint32_t npix = rc.width * rc.height, total = npix * batch_spp;
+    uint64_t seed = ((uint64_t)rc.seed_hi << 32) | rc.seed_lo;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { q.counts[0] = total; q.counts[1] = 0; }
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < total; i += gridDim.x * RT_BLOCK) {
+        uint32_t pix = i % npix, sidx = i / npix;
+        uint32_t x = pix % rc.width, y = pix / rc.width;
+        Pcg g = sample_stream(seed, rc.first_sample + sidx, x, y);
+        f3 o, d;
+        camera_ray(cam, x, y, g, o, d);
+        q.ray_o[0][i] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
+        q.ray_d[0][i] = make_float4(d.x, d.y, d.z, __uint_as_float(0u));
+        q.thr[0][i] = make_float4(1.f, 1.f, 1.f, 0.f);
+        q.rad[0][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        q.rng[0][i] = make_uint4((uint32_t)g.state, (uint32_t)(g.state >> 32), (uint32_t)g.inc, (uint32_t)(g.inc >> 32));
+    }
+}
+
+// Extend: closest hit of every live path of queue `cur`.
+template <int FEAT>
+__global__ __launch_bounds__(RT_BLOCK) void k_wf_extend(RtDevScene s, WfQueues q, int cur) {
+    __shared__ uint32_t stack[RT_STACK_DEPTH * RT_BLOCK];
+    uint32_t count = q.counts[cur];
+    if (blockIdx.x == 0 && threadIdx.x == 0) q.counts[cur ^ 1] = 0;   // shade appends to the other queue
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < count; i += gridDim.x * RT_BLOCK) {
+        float4 ro = q.ray_o[cur][i], rd = q.ray_d[cur][i];
+        uint64_t key = 0;
+        if (FEAT & RT_FEAT_XPRIM) {
+            uint4 r = q.rng[cur][i];
+            key = ((uint64_t)r.y << 32) | r.x;
+        }
+        Best b;
+        bool found = trace<!(FEAT & RT_FEAT_XPRIM)>(s, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), RT_T_MIN, RT_INF, key,
+                                                   nullptr, 0, stack + threadIdx.x, b);
+        q.hit[i] = make_float4(b.t, __uint_as_float(found ? b.ref : RT_REF_NONE), __uint_as_float(b.code), 0.f);
+    }
+}
+
+// Shade: scatter every live path of queue `cur`; survivors are appended, densely, to the
+// other queue (wave ballot + one atomic per wave); finished samples go to their slot.
+template <int FEAT>
+__global__ __launch_bounds__(RT_BLOCK) void k_wf_shade(RtDevScene s, WfQueues q, int cur, uint32_t background,
+                                                        uint32_t max_depth) {
+    const uint32_t lane = lane_id();
+    const uint32_t wave = (blockIdx.x * RT_BLOCK + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * RT_BLOCK) >> 6;
+    const uint32_t count = q.counts[cur];
+    const int nxt = cur ^ 1;
+    for (uint32_t base = wave * 64u; base < count; base += n_waves * 64u) {
+        uint32_t i = base + lane;
+        bool survive = false;
+        f3 o, d, thr, rad;
+        uint32_t pid = 0, depth = 0;
+        Pcg g;
+        g.state = g.inc = 0;
+        if (i < count) {
+            float4 ro = q.ray_o[cur][i], rd = q.ray_d[cur][i], t4 = q.thr[cur][i], r4 = q.rad[cur][i], h4 = q.hit[i];
+            uint4 rr = q.rng[cur][i];
+            o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z);
+            thr = mk3(t4.x, t4.y, t4.z); rad = mk3(r4.x, r4.y, r4.z);
+            pid = __float_as_uint(ro.w); depth = __float_as_uint(rd.w);
+            g.state = ((uint64_t)rr.y << 32) | rr.x;
+            g.inc = ((uint64_t)rr.w << 32) | rr.z;
+            Best b;
+            b.t = h4.x; b.ref = __float_as_uint(h4.y); b.code = __float_as_uint(h4.z);
+            survive = shade_path<FEAT>(s, background, max_depth, b.ref != RT_REF_NONE, b, o, d, thr, rad, depth, g);
+            if (!survive) q.sample_rad[pid] = make_float4(rad.x, rad.y, rad.z, 0.f);
+        }
+        uint64_t mask = __ballot(survive);
+        if (mask) {
+            uint32_t slot0 = 0;
+            if (lane == 0) slot0 = atomicAdd(&q.counts[nxt], (uint32_t)__popcll(mask));
+            slot0 = __shfl(slot0, 0);
+            if (survive) {
+                uint32_t j = slot0 + prefix_rank(mask);
+                q.ray_o[nxt][j] = make_float4(o.x, o.y, o.z, __uint_as_float(pid));
+                q.ray_d[nxt][j] = make_float4(d.x, d.y, d.z, __uint_as_float(depth));
+                q.thr[nxt][j] = make_float4(thr.x, thr.y, thr.z, 0.f);
+                q.rad[nxt][j] = make_float4(rad.x, rad.y, rad.z, 0.f);
+                q.rng[nxt][j] = make_uint4((uint32_t)g.state, (uint32_t)(g.state >> 32), (uint32_t)g.inc, (uint32_t)(g.inc >> 32));
+            }
+        }
+    }
+}
+
+// Accumulate: per pixel, the batch's samples in sample order, then into the accumulator.
+__global__ __launch_bounds__(RT_BLOCK) void k_wf_accumulate(const float4 *sample_rad, uint32_t npix, uint32_t batch_spp,
+                                                             float *accum) {
+    uint32_t p = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (p >= npix) return;
+    float r = 0.f, g = 0.f, b = 0.f;
+    for (uint32_t k = 0; k < batch_spp; k++) {
+        float4 v = sample_rad[(size_t)k * npix + p];
+        r += v.x; g += v.y; b += v.z;
+    }
+    accum[3 * (size_t)p + 0] += r;
+    accum[3 * (size_t)p + 1] += g;
+    accum[3 * (size_t)p + 2] += b;
+}
+
+// ------------------------------------------------------------------ fused persistent kernel
+template <int FEAT>
+__global__ __launch_bounds__(RT_BLOCK) void k_fused(RtDevScene s, RtDevCamera cam, RtDevRender rc, float *accum,
+                                                     uint32_t *counter, uint32_t n_items, uint32_t tiles_x,
+                                                     uint32_t n_tiles, uint32_t chunk_spp) {
+    __shared__ uint32_t stack[RT_STACK_DEPTH * RT_BLOCK];
+    __shared__ float tile_acc[RT_WAVES][192];
+    const uint32_t lane = lane_id();
+    float *acc = tile_acc[threadIdx.x >> 6];
+    const uint64_t seed = ((uint64_t)rc.seed_hi << 32) | rc.seed_lo;
+    while (true) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(counter, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;              // every wave reaches this: the grid drains
+        const uint32_t tile = item % n_tiles, chunk = item / n_tiles;
+        const uint32_t s_begin = chunk * chunk_spp;
+        const uint32_t s_end = min(rc.spp, s_begin + chunk_spp);
+        const uint32_t total = (s_end - s_begin) * 64u;
+        const uint32_t tx0 = (tile % tiles_x) * 8u, ty0 = (tile / tiles_x) * 8u;
+        acc[lane] = 0.f; acc[lane + 64] = 0.f; acc[lane + 128] = 0.f;
+        uint32_t next = 0;
+        bool alive = false;
+        f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(0, 0, 0), rad = mk3(0, 0, 0);
+        uint32_t depth = 0, pix = 0;
+        Pcg g;
+        g.state = g.inc = 0;
+        while (true) {
+            // ---- raygen phase: lanes without a path take the tile's next samples
+            uint64_t need = __ballot(!alive);
+            if (!alive) {
+                uint32_t k = next + prefix_rank(need);
+                if (k < total) {
+                    pix = k & 63u;
+                    uint32_t x = tx0 + (pix & 7u), y = ty0 + (pix >> 3);
+                    if (x < rc.width && y < rc.height) {
+                        g = sample_stream(seed, rc.first_sample + s_begin + (k >> 6), x, y);
+                        camera_ray(cam, x, y, g, o, d);
+                        thr = mk3(1, 1, 1);
+                        rad = mk3(0, 0, 0);
+                        depth = 0;
+                        alive = true;
+                    }
+                }
+            }
+            next += (uint32_t)__popcll(need);
+            if (!__any(alive)) {
+                if (next >= total) break;
+                continue;
+            }
+            // ---- extend + shade phases
+            if (alive) {
+                Best b;
+                bool found = trace<!(FEAT & RT_FEAT_XPRIM)>(s, o, d, RT_T_MIN, RT_INF, g.state, nullptr, 0,
+                                                           stack + threadIdx.x, b);
+                alive = shade_path<FEAT>(s, cam.background, rc.max_depth, found, b, o, d, thr, rad, depth, g);
+                if (!alive) {
+                    // ---- accumulate phase (LDS atomics: lanes of the wave may share a pixel)
+                    atomicAdd(&acc[3u * pix + 0u], rad.x);
+                    atomicAdd(&acc[3u * pix + 1u], rad.y);
+                    atomicAdd(&acc[3u * pix + 2u], rad.z);
+                }
+            }
+        }
+        // flush the tile (other chunks of the same tile may be in flight elsewhere)
+        {
+            uint32_t x = tx0 + (lane & 7u), y = ty0 + (lane >> 3);
+            if (x < rc.width && y < rc.height) {
+                float *dst = accum + 3 * ((size_t)y * rc.width + x);
+                atomicAdd(dst + 0, acc[3u * lane + 0u]);
+                atomicAdd(dst + 1, acc[3u * lane + 1u]);
+                atomicAdd(dst + 2, acc[3u * lane + 2u]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+size_t rt_wavefront_bytes(uint32_t capacity) {
+    return 256 + (size_t)capacity * (2 * 5 * 16 + 16 + 16);
+}
+
+void rt_wavefront_carve(void *workspace, uint32_t capacity, RtWavefrontBuffers &b) {
+    char *p = (char *)workspace;
+    b.counts = (uint32_t *)p;
+    p += 256;
+    size_t stride = (size_t)capacity * 16;
+    for (int k = 0; k < 2; k++) {
+        b.ray_o[k] = (float4 *)p; p += stride;
+        b.ray_d[k] = (float4 *)p; p += stride;
+        b.thr[k] = (float4 *)p; p += stride;
+        b.rad[k] = (float4 *)p; p += stride;
+        b.rng[k] = (uint4 *)p; p += stride;
+    }
+    b.hit = (float4 *)p; p += stride;
+    b.sample_rad = (float4 *)p;
+    b.capacity = capacity;
+}
+
+static inline int blocks_for(size_t n) { return (int)((n + RT_BLOCK - 1) / RT_BLOCK); }
+
+hipError_t rt_launch_first_hit(const RtDevScene &s, uint32_t feat, const float *rays, int n, float tmin, float tmax,
+                               uint64_t volume_key, RtHit *out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    if (feat & RT_FEAT_XPRIM)
+        k_first_hit<3><<<blocks_for(n), RT_BLOCK, 0, stream>>>(s, rays, n, tmin, tmax, volume_key, out);
+    else
+        k_first_hit<2><<<blocks_for(n), RT_BLOCK, 0, stream>>>(s, rays, n, tmin, tmax, volume_key, out);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_intervals(const RtDevScene &s, uint32_t ref, const float *rays, int n, const float *scripted,
+                               int n_scripted, uint64_t volume_key, uint32_t object, RtEvent *events, int32_t *counts,
+                               hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    k_intervals<<<blocks_for(n), RT_BLOCK, 0, stream>>>(s, ref, rays, n, scripted, n_scripted, volume_key, object, events, counts);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_camera_rays(const RtDevCamera &cam, const RtDevRender &rc, int x0, int y0, int w, int h,
+                                 float *rays_out, hipStream_t stream) {
+    size_t total = (size_t)w * h * rc.spp;
+    if (total == 0) return hipSuccess;
+    k_camera_rays<<<blocks_for(total), RT_BLOCK, 0, stream>>>(cam, rc, x0, y0, w, h, rays_out);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_resolve(const float *accum, float inv_samples, int width, int height, uint8_t *rgbx, hipStream_t stream) {
+    int npix = width * height;
+    if (npix <= 0) return hipSuccess;
+    k_resolve<<<blocks_for(npix), RT_BLOCK, 0, stream>>>(accum, inv_samples, npix, rgbx);
+    return hipGetLastError();
+}
+
+static int device_cus() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+}
+
+template <int FEAT>
+static hipError_t wavefront_batch(const RtDevScene &s, const RtDevCamera &cam, const RtDevRender &rc, uint32_t batch_spp,
+                                  const WfQueues &q, float *accum, hipStream_t stream, RtKernelTimer *timer, int grid) {
+    uint32_t npix = rc.width * rc.height;
+    k_wf_raygen<<<grid, RT_BLOCK, 0, stream>>>(q, cam, rc, batch_spp);
+    for (uint32_t bounce = 0; bounce < rc.max_depth; bounce++) {
+        int cur = (int)(bounce & 1u);
+        if (timer) timer->begin(stream);
+        k_wf_extend<FEAT><<<grid, RT_BLOCK, 0, stream>>>(s, q, cur);
+        if (timer) timer->end(stream);
+        k_wf_shade<FEAT><<<grid, RT_BLOCK, 0, stream>>>(s, q, cur, cam.background, rc.max_depth);
+        // the queues drain geometrically: look at the live count now and then, and stop early
+        if (bounce >= 7 && (bounce & 3u) == 3u && bounce + 1 < rc.max_depth) {
+            uint32_t live = 0;
+            hipError_t e = hipMemcpyAsync(&live, q.counts + (cur ^ 1), sizeof(live), hipMemcpyDeviceToHost, stream);
+            if (e != hipSuccess) return e;
+            e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return e;
+            if (live == 0) break;
+        }
+    }
+    k_wf_accumulate<<<blocks_for(npix), RT_BLOCK, 0, stream>>>(q.sample_rad, npix, batch_spp, accum);
+    return hipGetLastError();
+}
+
+hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc, float *accum,
+                               void *workspace, size_t workspace_bytes, hipStream_t stream, RtKernelTimer *timer) {
+    uint32_t npix = rc.width * rc.height;
+    if (npix == 0 || rc.spp == 0) return hipSuccess;
+    if (workspace_bytes < rt_wavefront_bytes(npix)) return hipErrorInvalidValue;
+    uint32_t max_batch = (uint32_t)std::min<size_t>(RT_WAVEFRONT_BATCH_SPP, (workspace_bytes - 256) / ((size_t)npix * 192));
+    RtWavefrontBuffers b;
+    rt_wavefront_carve(workspace, npix * max_batch, b);
+    WfQueues q;
+    for (int k = 0; k < 2; k++) { q.ray_o[k] = b.ray_o[k]; q.ray_d[k] = b.ray_d[k]; q.thr[k] = b.thr[k]; q.rad[k] = b.rad[k]; q.rng[k] = b.rng[k]; }
+    q.hit = b.hit; q.sample_rad = b.sample_rad; q.counts = b.counts;
+    if (timer) timer->name = "k_wf_extend";
+    uint32_t total_spp = rc.spp, first = rc.first_sample;
+    for (uint32_t s0 = 0; s0 < total_spp; s0 += max_batch) {
+        uint32_t batch = std::min(max_batch, total_spp - s0);
+        RtDevRender r = rc;
+        r.first_sample = first + s0;
+        r.spp = batch;
+        int grid = std::min(blocks_for((size_t)npix * batch), device_cus() * 8);
+        hipError_t e;
+        switch (feat & 3u) {
+        case 0: e = wavefront_batch<0>(s, cam, r, batch, q, accum, stream, timer, grid); break;
+        case 1: e = wavefront_batch<1>(s, cam, r, batch, q, accum, stream, timer, grid); break;
+        case 2: e = wavefront_batch<2>(s, cam, r, batch, q, accum, stream, timer, grid); break;
+        default: e = wavefront_batch<3>(s, cam, r, batch, q, accum, stream, timer, grid); break;
+        }
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+template <int FEAT>
+static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, const RtDevRender &rc, float *accum,
+                               uint32_t *counter, hipStream_t stream, RtKernelTimer *timer) {
+    uint32_t tiles_x = (rc.width + 7u) / 8u, tiles_y = (rc.height + 7u) / 8u, n_tiles = tiles_x * tiles_y;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
+    int grid = device_cus() * occ;
+    // enough work items that the dynamic queue evens out the waves: >= 8 per resident wave
+    uint32_t want_items = (uint32_t)grid * RT_WAVES * 8u;
+    uint32_t n_chunks = std::max(1u, std::min((want_items + n_tiles - 1u) / n_tiles, std::max(1u, rc.spp / 16u)));
+    uint32_t chunk_spp = (rc.spp + n_chunks - 1u) / n_chunks;
+    n_chunks = (rc.spp + chunk_spp - 1u) / chunk_spp;
+    uint32_t n_items = n_tiles * n_chunks;
+    grid = (int)std::min<uint32_t>((uint32_t)grid, (n_items + RT_WAVES - 1u) / RT_WAVES);
+    hipError_t e = hipMemsetAsync(counter, 0, 256, stream);
+    if (e != hipSuccess) return e;
+    if (timer) timer->begin(stream);
+    k_fused<FEAT><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp);
+    if (timer) timer->end(stream);
+    return hipGetLastError();
+}
+
+hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc, float *accum,
+                           void *workspace, size_t workspace_bytes, hipStream_t stream, RtKernelTimer *timer) {
+    if (rc.width == 0 || rc.height == 0 || rc.spp == 0) return hipSuccess;
+    if (workspace_bytes < RT_FUSED_WORKSPACE) return hipErrorInvalidValue;
+    if (timer) timer->name = "k_fused";
+    uint32_t *counter = (uint32_t *)workspace;
+    switch (feat & 3u) {
+    case 0: return fused_launch<0>(s, cam, rc, accum, counter, stream, timer);
+    case 1: return fused_launch<1>(s, cam, rc, accum, counter, stream, timer);
+    case 2: return fused_launch<2>(s, cam, rc, accum, counter, stream, timer);
+    default: return fused_launch<3>(s, cam, rc, accum, counter, stream, timer);
+    }
+}

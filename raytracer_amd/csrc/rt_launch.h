@@ -1,0 +1,89 @@
+// rt_launch.h - host-callable launchers of the HIP kernels (implemented in rt_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/raytracer_amd.h"
+#include "rt_shared.h"
+
+// Scene features that select a kernel specialisation.
+enum : uint32_t {
+    RT_FEAT_XPRIM = 1u,      // anything other than plain spheres in the BVH
+    RT_FEAT_TEXTURE = 2u,    // image or Perlin materials
+};
+
+// HIP events around every launch of the render loop's dominant kernel, on the stream the
+// kernel runs on.  Pairs are kept until collect() sums them (after synchronising).
+struct RtKernelTimer {
+    std::vector<hipEvent_t> pool;      // start0, stop0, start1, stop1, ...
+    size_t used = 0;
+    double total_ms = 0.0;
+    uint64_t launches = 0;
+    const char *name = "";
+    bool enabled = true;
+
+    void begin(hipStream_t st) {
+        if (!enabled) return;
+        if (used + 2 > pool.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { enabled = false; return; }
+            pool.push_back(a);
+            pool.push_back(b);
+        }
+        (void)hipEventRecord(pool[used], st);
+    }
+    void end(hipStream_t st) {
+        if (!enabled) return;
+        (void)hipEventRecord(pool[used + 1], st);
+        used += 2;
+    }
+    void collect() {
+        for (size_t i = 0; i + 1 < used; i += 2) {
+            float ms = 0.f;
+            if (hipEventSynchronize(pool[i + 1]) == hipSuccess && hipEventElapsedTime(&ms, pool[i], pool[i + 1]) == hipSuccess) {
+                total_ms += ms;
+                launches++;
+            }
+        }
+        used = 0;
+    }
+    void reset() { collect(); total_ms = 0.0; launches = 0; }
+    ~RtKernelTimer() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); }
+};
+
+// Layout of the wavefront pipeline's workspace for `capacity` paths.
+struct RtWavefrontBuffers {
+    float4 *ray_o[2], *ray_d[2], *thr[2], *rad[2];
+    uint4 *rng[2];
+    float4 *hit;
+    float4 *sample_rad;
+    uint32_t *counts;         // [0], [1]: live paths of queue 0 / 1
+    uint32_t capacity;
+};
+
+size_t rt_wavefront_bytes(uint32_t capacity);
+void rt_wavefront_carve(void *workspace, uint32_t capacity, RtWavefrontBuffers &out);
+
+hipError_t rt_launch_first_hit(const RtDevScene &s, uint32_t feat, const float *rays, int n, float tmin, float tmax,
+                               uint64_t volume_key, RtHit *out, hipStream_t stream);
+hipError_t rt_launch_intervals(const RtDevScene &s, uint32_t ref, const float *rays, int n, const float *scripted,
+                               int n_scripted, uint64_t volume_key, uint32_t object, RtEvent *events, int32_t *counts,
+                               hipStream_t stream);
+hipError_t rt_launch_camera_rays(const RtDevCamera &cam, const RtDevRender &rc, int x0, int y0, int w, int h,
+                                 float *rays_out, hipStream_t stream);
+hipError_t rt_launch_resolve(const float *accum, float inv_samples, int width, int height, uint8_t *rgbx, hipStream_t stream);
+
+// spp samples per pixel starting at rc.first_sample, added to accum.
+hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc,
+                               float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
+                               RtKernelTimer *timer);
+hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc,
+                           float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
+                           RtKernelTimer *timer);
+
+#define RT_WAVEFRONT_BATCH_SPP 8u      // samples per pixel resident in the path queues at once
+#define RT_FUSED_WORKSPACE 4096u

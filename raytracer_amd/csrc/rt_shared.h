@@ -1,0 +1,101 @@
+// rt_shared.h - plain-data layouts shared by the host flattener and the HIP kernels.
+//
+// Device layout (all buffers live in HBM, written once at rt_scene_commit):
+//   nodes      4 x float4 per BVH node: both child boxes and both child references, so one
+//              64-byte fetch serves two box tests.
+//   spheres    float4 (cx, cy, cz, r) per sphere: the whole geometry of the common case
+//              in one 16-byte load; material ids and UV rotations are separate streams
+//              that only the shade stage touches.
+//   xprims     4 x float4 per cylinder / cuboid / quad (rotation, translation, extents).
+//   prim_mat   per-face material ids of the xprims (6 per record), sphere_mat for spheres.
+//   csg / cdv  small records naming leaf primitives; a CSG tree is flattened to a truth
+//              table over its leaves.
+//   materials  2 x float4 per material; texels RGBA8; perlin tables as in the C ABI.
+#pragma once
+
+#include <stdint.h>
+
+#define RT_REF_NONE 0xFFFFFFFFu
+#define RT_REF_LEAF 0x80000000u
+#define RT_KIND_SHIFT 28
+#define RT_INDEX_MASK 0x0FFFFFFFu
+
+enum RtPrimKind : uint32_t {
+    RT_KIND_SPHERE = 0,
+    RT_KIND_CYLINDER = 1,
+    RT_KIND_CUBOID = 2,
+    RT_KIND_QUAD = 3,
+    RT_KIND_CSG = 4,
+    RT_KIND_CDV = 5,
+};
+
+#define RT_STACK_DEPTH 32        // traversal stack entries per lane (LDS)
+#define RT_BLOCK 256             // threads per workgroup of every traversal kernel
+#define RT_CSG_LEAVES 8
+
+static inline uint32_t rt_make_ref(uint32_t kind, uint32_t index) { return (kind << RT_KIND_SHIFT) | index; }
+
+struct RtDevCsg {
+    uint32_t n_leaves;
+    uint32_t flip_mask;                 // bit i: leaf i sits under an odd number of subtract right-hand sides
+    uint32_t leaf[RT_CSG_LEAVES];       // primitive references (kind | index), depth-first order
+    uint32_t truth[8];                  // inside(root) for every leaf-membership mask (256 bits)
+};
+
+struct RtDevCdv {
+    uint32_t base;                      // primitive or CSG reference
+    float neg_inv_density;
+};
+
+struct RtDevTexture {
+    uint32_t offset;                    // first texel in the RGBA8 pool
+    uint32_t width, height, pad;
+};
+
+struct RtDevPerlin {
+    float colors[2][3];
+    float frequency;
+    uint32_t turbulence;
+    float vectors[256][3];
+    uint8_t permutations[3][256];
+};
+
+// Everything a kernel needs to trace and shade; passed by value.
+struct RtDevScene {
+    const float *nodes;            // n_nodes x 16 floats
+    const float *spheres;          // n x 4
+    const float *sphere_rot;       // n x 12 (three padded columns) or nullptr when every rotation is identity
+    const uint32_t *sphere_mat;
+    const uint32_t *sphere_obj;
+    const float *xprims;           // n x 16
+    const uint32_t *xprim_mat;     // n x 6
+    const uint32_t *xprim_obj;
+    const RtDevCsg *csg;
+    const uint32_t *csg_obj;
+    const RtDevCdv *cdv;
+    const uint32_t *cdv_obj;
+    const float *materials;        // n x 8
+    const RtDevTexture *textures;
+    const uint32_t *texels;
+    const RtDevPerlin *perlin;
+    uint32_t root;                 // child reference of the root (RT_REF_NONE for an empty scene)
+    uint32_t n_nodes;
+};
+
+// Camera as the kernels use it (Shaders.metal:20-48 computed once on the host instead of
+// once per thread).
+struct RtDevCamera {
+    float center[3];
+    float viewport_u[3], viewport_v[3], viewport_center[3];
+    float defocus_u[3], defocus_v[3];
+    float inv_w, inv_h;
+    uint32_t defocus;        // 1 when defocus_angle > 0
+    uint32_t background;
+};
+
+struct RtDevRender {
+    uint32_t width, height;
+    uint32_t spp, max_depth;
+    uint32_t first_sample;
+    uint32_t seed_lo, seed_hi;
+};

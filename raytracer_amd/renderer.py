@@ -1,0 +1,203 @@
+"""Renderer: the host object that owns a flattened scene and drives the render loop.
+
+Mirrors `Renderer` of the reference app (MetalRayTracer/ContentView.swift:103-235): built
+once from a Scene (flatten + acceleration structure, :122-170), then `draw` adds one pass
+to a per-pixel accumulator (:182-224).  Device memory and streams come from torch; every
+computation happens in the native library.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import abi
+from ._native import check, lib
+from .scene import RenderConfig
+
+HIT_DTYPE = np.dtype([("t", "f4"), ("point", "f4", 3), ("normal", "f4", 3), ("uv", "f4", 2),
+                      ("object", "i4"), ("material_offset", "u4"), ("front_face", "i4")])
+EVENT_DTYPE = np.dtype([("t", "f4"), ("point", "f4", 3), ("normal", "f4", 3), ("uv", "f4", 2),
+                        ("material_offset", "u4"), ("is_exit", "i4"), ("pad", "i4")])
+assert HIT_DTYPE.itemsize == 48 and EVENT_DTYPE.itemsize == 48
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Context:
+    def __init__(self, device_ordinal=0):
+        self.device_ordinal = device_ordinal
+        self.device = torch.device("cuda", device_ordinal)
+        torch.cuda.set_device(self.device)
+        self.h = C.c_void_p()
+        check(lib.rt_context_create(device_ordinal, C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.rt_context_destroy(self.h)
+            self.h = None
+
+
+class NativeScene:
+    """Encoder sink that forwards the C records to the library (see scene.SceneEncoder)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        check(lib.rt_scene_create(ctx.h, C.byref(self.h)))
+        self.committed = False
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.rt_scene_destroy(self.h)
+            self.h = None
+
+    # ---- sink protocol
+    def add_material(self, rec):
+        return check(lib.rt_add_material(self.h, C.byref(rec), C.sizeof(rec)))
+
+    def add_dummy_materials(self, n):
+        for _ in range(n):
+            self.add_material(abi.RtColoredLambertianMaterial(abi.material_kind_lambertian_colored, abi.F3(.5, .5, .5)))
+
+    def add_texture_rgb8(self, w, h, pixels):
+        buf = np.ascontiguousarray(pixels, dtype=np.uint8)
+        return check(lib.rt_add_texture_rgb8(self.h, w, h, buf.ctypes.data_as(C.c_void_p)))
+
+    def shape_sphere(self, rec):
+        return check(lib.rt_shape_sphere(self.h, C.byref(rec)))
+
+    def shape_cylinder(self, rec):
+        return check(lib.rt_shape_cylinder(self.h, C.byref(rec)))
+
+    def shape_cuboid(self, rec):
+        return check(lib.rt_shape_cuboid(self.h, C.byref(rec)))
+
+    def shape_quad(self, rec):
+        return check(lib.rt_shape_quad(self.h, C.byref(rec)))
+
+    def shape_csg(self, op, ids):
+        arr = (C.c_int * len(ids))(*ids)
+        return check(lib.rt_shape_csg(self.h, op, len(ids), arr))
+
+    def shape_cdv(self, base, density):
+        return check(lib.rt_shape_cdv(self.h, base, density))
+
+    def add_object(self, shape):
+        return check(lib.rt_add_object(self.h, shape))
+
+    def add_spheres_bulk(self, centers, radii, mat_ids):
+        cr = np.ascontiguousarray(np.concatenate([centers, radii[:, None]], axis=1), dtype=np.float32)
+        m = np.ascontiguousarray(mat_ids, dtype=np.uint32)
+        return check(lib.rt_add_sphere_objects(self.h, len(m), cr.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p)))
+
+    def commit(self):
+        check(lib.rt_scene_commit(self.h))
+        self.committed = True
+
+    def stats(self):
+        st = abi.RtSceneStats()
+        check(lib.rt_scene_stats(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    # ---- queries
+    def _rays_dev(self, rays):
+        if isinstance(rays, torch.Tensor):
+            t = rays.to(device=self.ctx.device, dtype=torch.float32).contiguous()
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(rays, dtype=np.float32)).to(self.ctx.device)
+        return t.reshape(-1, 6)
+
+    def first_hit(self, rays, tmin=1e-3, tmax=float("inf"), volume_key=0):
+        """Closest hit of each ray; returns a numpy structured array (HIT_DTYPE)."""
+        r = self._rays_dev(rays)
+        n = r.shape[0]
+        out = torch.zeros(max(n, 1) * 48, dtype=torch.uint8, device=self.ctx.device)
+        check(lib.rt_first_hit(self.h, r.data_ptr(), n, tmin, tmax, volume_key, out.data_ptr(), _stream()))
+        torch.cuda.synchronize(self.ctx.device)
+        return out.cpu().numpy()[: n * 48].view(HIT_DTYPE)
+
+    def intervals(self, shape, rays, scripted=None, volume_key=0):
+        """Ordered boundary crossings of `shape` along each ray: list of event arrays."""
+        r = self._rays_dev(rays)
+        n = r.shape[0]
+        ev = torch.zeros(max(n, 1) * abi.RT_MAX_EVENTS * 48, dtype=torch.uint8, device=self.ctx.device)
+        cnt = torch.zeros(max(n, 1), dtype=torch.int32, device=self.ctx.device)
+        s_ptr, s_n = None, 0
+        if scripted:
+            s = torch.tensor(list(scripted), dtype=torch.float32, device=self.ctx.device)
+            s_ptr, s_n = s.data_ptr(), len(scripted)
+        check(lib.rt_intervals(self.h, shape, r.data_ptr(), n, s_ptr, s_n, volume_key, ev.data_ptr(), cnt.data_ptr(),
+                               _stream()))
+        torch.cuda.synchronize(self.ctx.device)
+        evs = ev.cpu().numpy().view(EVENT_DTYPE).reshape(-1, abi.RT_MAX_EVENTS)
+        cnts = cnt.cpu().numpy()
+        return [evs[i, : cnts[i]] for i in range(n)]
+
+
+def camera_rays(ctx, camera, config, width, height, window=None):
+    x0, y0, w, h = window if window else (0, 0, width, height)
+    n = w * h * config.samples_per_pixel
+    out = torch.zeros((max(n, 1), 6), dtype=torch.float32, device=ctx.device)
+    cc, rc = camera.impl, config.impl
+    check(lib.rt_camera_rays(ctx.h, C.byref(cc), C.byref(rc), width, height, x0, y0, w, h, out.data_ptr(), _stream()))
+    torch.cuda.synchronize(ctx.device)
+    return out[:n].cpu().numpy()
+
+
+class Renderer:
+    """ContentView.swift:103-235.  `draw` = one pass of `samples_per_pixel` samples added to
+    the float accumulator; the accumulator resets when the size changes (:172-180)."""
+
+    def __init__(self, scene, width, height, pipeline=abi.RT_PIPELINE_FUSED, device_ordinal=0, ctx=None, dedup=True):
+        self.ctx = ctx or Context(device_ordinal)
+        self.scene = scene
+        self.camera = scene.camera
+        self.native = NativeScene(self.ctx)
+        scene.encode(self.native, dedup=dedup)
+        self.native.commit()
+        self.pipeline = pipeline
+        self.pass_counter = 0
+        self.samples = 0
+        self.resize(width, height)
+
+    def resize(self, width, height):
+        self.width, self.height = width, height
+        self.accum = torch.zeros((height, width, 3), dtype=torch.float32, device=self.ctx.device)
+        ws = lib.rt_render_workspace_size(self.pipeline, width, height)
+        self.workspace = torch.empty(max(ws, 256), dtype=torch.uint8, device=self.ctx.device)
+        self.pass_counter = 0
+        self.samples = 0
+
+    def reset(self):
+        self.accum.zero_()
+        self.pass_counter = 0
+        self.samples = 0
+
+    def draw(self, samples_per_pixel=1, max_depth=10, rng_seed=0, first_sample=None):
+        """Adds one pass.  `first_sample` defaults to the number of samples already held, so
+        successive passes continue one stream of samples."""
+        self.pass_counter += 1
+        first = self.samples if first_sample is None else first_sample
+        rc = RenderConfig(samples_per_pixel, max_depth, self.pass_counter, rng_seed, first).impl
+        cc = self.camera.impl
+        check(lib.rt_render(self.native.h, C.byref(cc), C.byref(rc), self.pipeline, self.width, self.height,
+                            self.accum.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(), _stream()))
+        self.samples += samples_per_pixel
+
+    def mean(self):
+        """Per-pixel mean radiance, [H, W, 3] float32 on the device."""
+        return self.accum / max(self.samples, 1)
+
+    def image_rgb8(self):
+        out = torch.empty((self.height, self.width, 4), dtype=torch.uint8, device=self.ctx.device)
+        check(lib.rt_resolve_rgb8(self.ctx.h, self.accum.data_ptr(), max(self.samples, 1), self.width, self.height,
+                                  out.data_ptr(), _stream()))
+        torch.cuda.synchronize(self.ctx.device)
+        return out[..., :3].cpu().numpy()
+
+    def kernel_time(self, reset=False):
+        ms, n, name = C.c_double(), C.c_uint64(), C.c_char_p()
+        check(lib.rt_kernel_time(self.native.h, 1 if reset else 0, C.byref(ms), C.byref(n), C.byref(name)))
+        return ms.value, n.value, (name.value or b"").decode()
