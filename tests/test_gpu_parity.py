@@ -58,18 +58,28 @@ def test_reference_known_answers(ctx, case):
         check_event(ev, ex, tol, "%s[%d]" % (case["name"], i))
 
 
-def _reach(scene_obj_boxes, rays, hits):
-    return None
+def bounding_spheres(scene):
+    """Centre and radius of every object's bounding box (host API boxes)."""
+    c, r = [], []
+    for obj in scene.objects:
+        b = obj.bounding_box
+        lo, hi = b.min.astype(np.float64), b.max.astype(np.float64)
+        c.append((lo + hi) / 2)
+        r.append(np.linalg.norm(hi - lo) / 2)
+    return np.array(c), np.array(r)
 
 
-def compare_first_hits(gpu, ref, rays, rel=1e-5, max_bad_frac=2e-3, what=""):
+def compare_first_hits(gpu, ref, rays, scene, rel=1e-5, max_bad_frac=2e-3, what=""):
     """gpu: HIT_DTYPE array (float32), ref: oracle HIT_DTYPE (float64)."""
     n = len(rays)
     same_obj = gpu["object"] == ref["object"]
     both_hit = same_obj & (ref["object"] >= 0)
     o = rays[:, :3].astype(np.float64)
-    # scale of the problem per ray: distance to the hit point plus the coordinates involved
-    scale = np.maximum(np.abs(ref["t"]), np.linalg.norm(o, axis=1) + np.linalg.norm(ref["point"], axis=1))
+    # reach: from the ray origin to the far side of the hit object's bounding sphere
+    bc, br = bounding_spheres(scene)
+    idx = np.maximum(ref["object"], 0)
+    reach = np.linalg.norm(o - bc[idx], axis=1) + br[idx]
+    scale = np.maximum(np.abs(ref["t"]), reach)
     dt = np.abs(gpu["t"].astype(np.float64) - ref["t"])
     ok_t = dt <= rel * np.maximum(scale, 1e-3)
     strict = dt <= rel * np.maximum(np.abs(ref["t"]), 1e-3)
@@ -106,7 +116,7 @@ def test_first_hit_demo_scenes(ctx, name):
     rays = np.concatenate([cam, rnd]).astype(np.float32)
     g = nat.first_hit(rays, tmin=1e-3)
     r = orc.first_hit(rays, tmin=1e-3, precision=ob.ORC_F64)
-    info = compare_first_hits(g, r, rays, what=name)
+    info = compare_first_hits(g, r, rays, scene, what=name)
     assert info["hits"] > 100
 
 
@@ -125,7 +135,7 @@ def test_first_hit_random_spheres(ctx):
     rays = np.concatenate([cam, rnd]).astype(np.float32)
     g = nat.first_hit(rays)
     r = orc.first_hit(rays, precision=ob.ORC_F64)
-    compare_first_hits(g, r, rays, what="random_spheres")
+    compare_first_hits(g, r, rays, scene, what="random_spheres")
 
 
 def test_first_hit_cornell_and_quads_volume_boundaries(ctx):
@@ -142,7 +152,7 @@ def test_first_hit_cornell_and_quads_volume_boundaries(ctx):
         key = 0x9E3779B97F4A7C15
         g = nat.first_hit(rays, volume_key=key)
         r = orc.first_hit(rays, precision=ob.ORC_F64, volume_key=key)
-        compare_first_hits(g, r, rays, what=name, rel=2e-5)
+        compare_first_hits(g, r, rays, scene, what=name, rel=2e-5)
 
 
 def test_intervals_csg_random_rays(ctx):
