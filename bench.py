@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--pipeline", default="fused", choices=["fused", "wavefront"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel per step (0 = the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bvh", default="sah", choices=["sah", "median"])
+    ap.add_argument("--refill", type=int, default=0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -84,7 +86,8 @@ def main():
     if args.spp:
         spp = args.spp
     pipeline = abi.RT_PIPELINE_FUSED if args.pipeline == "fused" else abi.RT_PIPELINE_WAVEFRONT
-    r = Renderer(scene, w, h, pipeline=pipeline, device_ordinal=local_rank)
+    r = Renderer(scene, w, h, pipeline=pipeline, device_ordinal=local_rank,
+                 bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_MEDIAN_SPLIT, refill=args.refill or None)
 
     def step(i):
         # rank g renders sample indices [ (i*world + g)*spp, +spp ): disjoint over ranks and steps

@@ -221,6 +221,15 @@ int rt_add_sphere_objects(RtScene *, int n, const float *center_radius, const ui
 int rt_scene_commit(RtScene *);
 int rt_scene_stats(const RtScene *, RtSceneStats *out);
 
+/* Tuning knobs; no counterpart in the reference (Metal's acceleration structure is opaque).
+ * RT_OPTION_BVH_BUILDER (before commit): RT_BVH_MEDIAN_SPLIT is the reference's rule
+ * (RayTracingKit/Hittable.swift:609-631), RT_BVH_SAH (default) a binned surface-area
+ * heuristic; hit results do not depend on the choice.  RT_OPTION_REFILL_THRESHOLD: how many
+ * lanes of a wave must be waiting before the fused kernel leaves its traversal loop. */
+enum RtOption { RT_OPTION_BVH_BUILDER = 1, RT_OPTION_REFILL_THRESHOLD = 2 };
+enum RtBvhBuilder { RT_BVH_MEDIAN_SPLIT = 0, RT_BVH_SAH = 1 };
+int rt_scene_set_option(RtScene *, int option, int value);
+
 /* ---- queries (parity surface) ------------------------------------------------ */
 
 /* Closest hit of n rays (rays_dev: n x 6 floats, origin then direction) with

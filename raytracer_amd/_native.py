@@ -14,7 +14,7 @@ EXPORTS = [
     "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_abi_version",
     "rt_scene_create", "rt_scene_destroy", "rt_add_material", "rt_add_texture_rgb8",
     "rt_shape_sphere", "rt_shape_cylinder", "rt_shape_cuboid", "rt_shape_quad", "rt_shape_csg", "rt_shape_cdv",
-    "rt_add_object", "rt_add_sphere_objects", "rt_scene_commit", "rt_scene_stats",
+    "rt_add_object", "rt_add_sphere_objects", "rt_scene_commit", "rt_scene_stats", "rt_scene_set_option",
     "rt_first_hit", "rt_intervals", "rt_camera_rays",
     "rt_render_workspace_size", "rt_render", "rt_resolve_rgb8", "rt_kernel_time",
 ]
@@ -50,6 +50,7 @@ def _load():
         "rt_add_sphere_objects": (i32, [vp, i32, vp, vp]),
         "rt_scene_commit": (i32, [vp]),
         "rt_scene_stats": (i32, [vp, C.POINTER(abi.RtSceneStats)]),
+        "rt_scene_set_option": (i32, [vp, i32, i32]),
         "rt_first_hit": (i32, [vp, vp, i32, f32, f32, u64, vp, vp]),
         "rt_intervals": (i32, [vp, i32, vp, i32, vp, i32, u64, vp, vp, vp]),
         "rt_camera_rays": (i32, [vp, C.POINTER(abi.RtCameraConfig), C.POINTER(abi.RtRenderConfig), i32, i32, i32, i32,

@@ -535,66 +535,97 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
 }
 
 // ------------------------------------------------------------------ BVH traversal (extend)
-// Node: 16 floats = left box (min xyz, max xyz), right box, left ref, right ref, 2 pad.
-// A reference with RT_REF_LEAF set names an object (kind | index), otherwise a node.
+// Node: 16 floats = for the left then the right child (min, max) pairs per axis
+// (x0,x1, y0,y1, z0,z1), then left ref, right ref, 2 pad.  The pairs let both slab
+// distances of an axis come out of one packed FMA: t = plane * (1/d) + (-o/d).
+// A reference with RT_REF_LEAF set names an object (kind | index), otherwise a node;
+// RT_REF_NONE doubles as "traversal finished".
 // The per-lane stack lives in LDS as stack[entry * RT_BLOCK + lane]: the 64 lanes of a
 // wave hit 64 consecutive banks whatever their individual depth.
-RT_DEV float box_entry(f3 bmin, f3 bmax, f3 o, f3 inv_d, float tmin, float tmax, bool &hit) {
-    float tx0 = (bmin.x - o.x) * inv_d.x, tx1 = (bmax.x - o.x) * inv_d.x;
-    float ty0 = (bmin.y - o.y) * inv_d.y, ty1 = (bmax.y - o.y) * inv_d.y;
-    float tz0 = (bmin.z - o.z) * inv_d.z, tz1 = (bmax.z - o.z) * inv_d.z;
-    // fminf/fmaxf drop a NaN operand (0 * inf on an axis-parallel ray lying in a box plane)
-    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
-    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct Trav {
+    f3 o, d;
+    f3 inv_d, oid;         // 1/d and -o/d
+    uint32_t cur;
+    int sp;
+    Best best;
+    bool found;
+};
+
+RT_DEV void trav_begin(Trav &t, uint32_t root, f3 o, f3 d, float tmax) {
+    t.o = o; t.d = d;
+    t.inv_d = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
+    t.oid = mk3(-o.x * t.inv_d.x, -o.y * t.inv_d.y, -o.z * t.inv_d.z);
+    t.cur = root;
+    t.sp = 0;
+    t.best.t = tmax;
+    t.best.ref = RT_REF_NONE;
+    t.best.code = 0;
+    t.found = false;
+}
+
+RT_DEV void trav_pop(Trav &t, const uint32_t *stack) {
+    if (t.sp == 0) { t.cur = RT_REF_NONE; return; }
+    t.sp--;
+    t.cur = stack[t.sp * RT_BLOCK];
+}
+
+// Entry distance of the ray into one child box, and whether it is hit within
+// [tmin, limit].  fminf/fmaxf drop a NaN operand (0 * inf when an axis-parallel ray lies
+// in a box plane), which leaves that axis unconstrained.
+RT_DEV float box_entry(v2f tx, v2f ty, v2f tz, float tmin, float limit, bool &hit) {
+    float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tmin));
+    float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), limit));
     hit = tn <= tf;
     return tn;
 }
 
+// One inner-node step: tests both children, goes to the nearer one, pushes the farther.
+RT_DEV void trav_node(const float4 *nodes, Trav &t, float tmin, uint32_t *stack) {
+    const float4 *n = nodes + 4u * t.cur;
+    float4 a = n[0], b = n[1], c = n[2], e = n[3];
+    v2f ix = {t.inv_d.x, t.inv_d.x}, iy = {t.inv_d.y, t.inv_d.y}, iz = {t.inv_d.z, t.inv_d.z};
+    v2f ox = {t.oid.x, t.oid.x}, oy = {t.oid.y, t.oid.y}, oz = {t.oid.z, t.oid.z};
+    v2f lx = {a.x, a.y}, ly = {a.z, a.w}, lz = {b.x, b.y};
+    v2f rx = {b.z, b.w}, ry = {c.x, c.y}, rz = {c.z, c.w};
+    bool hl, hr;
+    // a box farther than the closest hit so far cannot hold a closer one
+    float limit = t.best.t;
+    float tl = box_entry(lx * ix + ox, ly * iy + oy, lz * iz + oz, tmin, limit, hl);
+    float tr = box_entry(rx * ix + ox, ry * iy + oy, rz * iz + oz, tmin, limit, hr);
+    uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
+    hr = hr && rref != RT_REF_NONE;       // a single-object scene has no right child
+    if (hl && hr) {
+        bool left_first = tl <= tr;
+        stack[t.sp * RT_BLOCK] = left_first ? rref : lref;
+        t.sp++;
+        t.cur = left_first ? lref : rref;
+    } else if (hl) {
+        t.cur = lref;
+    } else if (hr) {
+        t.cur = rref;
+    } else {
+        trav_pop(t, stack);
+    }
+}
+
+// Runs one ray to completion (parity kernels and the wavefront extend stage).
 template <bool SIMPLE>
 RT_DEV bool trace(const RtDevScene &s, f3 o, f3 d, float tmin, float tmax, uint64_t volume_key,
                   const float *scripted, uint32_t n_scripted, uint32_t *stack, Best &best) {
-    bool found = false;
-    best.t = tmax;
-    best.ref = RT_REF_NONE;
-    best.code = 0;
-    uint32_t cur = s.root;
-    if (cur == RT_REF_NONE) return false;
-    f3 inv_d = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
-    int sp = 0;
+    Trav t;
+    trav_begin(t, s.root, o, d, tmax);
     const float4 *nodes = (const float4 *)s.nodes;
-    while (true) {
-        while (!(cur & RT_REF_LEAF)) {
-            const float4 *n = nodes + 4u * cur;
-            float4 a = n[0], b = n[1], c = n[2], e = n[3];
-            bool hl, hr;
-            // a box farther than the closest hit so far cannot hold a closer one
-            float limit = best.t;
-            float tl = box_entry(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), o, inv_d, tmin, limit, hl);
-            float tr = box_entry(mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), o, inv_d, tmin, limit, hr);
-            uint32_t lref = __float_as_uint(e.x), rref = __float_as_uint(e.y);
-            hl = hl && lref != RT_REF_NONE;
-            hr = hr && rref != RT_REF_NONE;
-            if (hl && hr) {
-                bool left_first = tl <= tr;
-                uint32_t nearer = left_first ? lref : rref, farther = left_first ? rref : lref;
-                stack[sp * RT_BLOCK] = farther;
-                sp++;
-                cur = nearer;
-            } else if (hl) {
-                cur = lref;
-            } else if (hr) {
-                cur = rref;
-            } else {
-                if (sp == 0) return found;
-                sp--;
-                cur = stack[sp * RT_BLOCK];
-            }
+    while (t.cur != RT_REF_NONE) {
+        while (!(t.cur & RT_REF_LEAF)) trav_node(nodes, t, tmin, stack);
+        if (t.cur != RT_REF_NONE) {
+            test_object<SIMPLE>(s, t.cur & ~RT_REF_LEAF, o, d, tmin, tmax, volume_key, scripted, n_scripted, t.found, t.best);
+            trav_pop(t, stack);
         }
-        test_object<SIMPLE>(s, cur & ~RT_REF_LEAF, o, d, tmin, tmax, volume_key, scripted, n_scripted, found, best);
-        if (sp == 0) return found;
-        sp--;
-        cur = stack[sp * RT_BLOCK];
     }
+    best = t.best;
+    return t.found;
 }
 
 // ------------------------------------------------------------------ surface of the closest hit

@@ -75,6 +75,8 @@ struct RtScene {
     // bulk spheres (kept as arrays: a million HostShape records would be wasteful)
     std::vector<float> bulk_spheres;       // cx, cy, cz, r
     std::vector<uint32_t> bulk_mats;
+    int bvh_builder = RT_BVH_SAH;
+    uint32_t refill = 48;
     bool committed = false;
     std::vector<void *> device_allocs;
     RtDevScene dev{};
@@ -172,7 +174,7 @@ void pad_box(Box3 &b) {
         if (!(b.mn[a] <= b.mx[a])) continue;    // empty (e.g. disjoint intersection): leave it
         float m = std::max(std::fabs(b.mn[a]), std::fabs(b.mx[a]));
         float pad = std::isfinite(m) ? 4e-6f * std::max(m, 1e-3f) : 0.f;
-        if (b.mx[a] - b.mn[a] < 1e-4f) pad = std::max(pad, 1e-4f);
+        if (b.mx[a] - b.mn[a] < 1e-4f) pad = std::max(1e-4f, std::isfinite(m) ? m * (1.f / 65536.f) : 0.f);
         b.mn[a] -= pad;
         b.mx[a] += pad;
     }
@@ -212,8 +214,79 @@ struct Builder {
     std::vector<BuildItem> items;
     std::vector<float> nodes;      // 16 floats per node
     uint32_t max_depth = 0;
+    bool sah = false;
 
-    static void put_box(float *dst, const Box3 &b) { for (int a = 0; a < 3; a++) { dst[a] = b.mn[a]; dst[3 + a] = b.mx[a]; } }
+    static void put_box(float *dst, const Box3 &b) { for (int a = 0; a < 3; a++) { dst[2 * a] = b.mn[a]; dst[2 * a + 1] = b.mx[a]; } }
+
+    static float half_area(const Box3 &b) {
+        float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+        if (!(dx >= 0.f) || !(dy >= 0.f) || !(dz >= 0.f)) return 0.f;      // empty
+        float a = dx * dy + dy * dz + dz * dx;
+        return std::isfinite(a) ? a : 3.0e38f;
+    }
+
+    // Reference rule, RayTracingKit/Hittable.swift:615-620: longest axis of the node's box
+    // (ties as AABB.swift:59-66), order by box centre, split at (n+1)/2.  Only the split
+    // matters (each half is re-ordered on its own axis one level down), so a selection
+    // stands in for the reference's full sort.
+    size_t split_median(size_t lo, size_t hi, const Box3 &all) {
+        float sx = all.mx[0] - all.mn[0], sy = all.mx[1] - all.mn[1], sz = all.mx[2] - all.mn[2];
+        int axis = sx > sy ? (sx > sz ? 0 : 2) : (sy > sz ? 1 : 2);
+        size_t mid = lo + (hi - lo + 1) / 2;
+        std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
+                         [axis](const BuildItem &a, const BuildItem &b) { return a.c[axis] < b.c[axis]; });
+        return mid;
+    }
+
+    // Binned surface-area heuristic (16 bins per axis on the box centres): minimises
+    // area(left)*count(left) + area(right)*count(right).  Returns lo when no split helps.
+    size_t split_sah(size_t lo, size_t hi) {
+        constexpr int BINS = 16;
+        float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = lo; i < hi; i++)
+            for (int a = 0; a < 3; a++) { cmin[a] = std::min(cmin[a], items[i].c[a]); cmax[a] = std::max(cmax[a], items[i].c[a]); }
+        float best_cost = INFINITY;
+        int best_axis = -1, best_bin = 0;
+        float best_scale = 0.f;
+        for (int axis = 0; axis < 3; axis++) {
+            float ext = cmax[axis] - cmin[axis];
+            if (!(ext > 0.f) || !std::isfinite(ext)) continue;
+            float scale = (float)BINS / ext;
+            Box3 bb[BINS];
+            uint32_t bc[BINS] = {0};
+            for (size_t i = lo; i < hi; i++) {
+                int b = std::min(BINS - 1, (int)((items[i].c[axis] - cmin[axis]) * scale));
+                bb[b].add(items[i].box);
+                bc[b]++;
+            }
+            float right_area[BINS];
+            uint32_t right_cnt[BINS];
+            Box3 acc;
+            uint32_t cnt = 0;
+            for (int b = BINS - 1; b > 0; b--) {
+                if (bc[b]) acc.add(bb[b]);
+                cnt += bc[b];
+                right_area[b] = half_area(acc);
+                right_cnt[b] = cnt;
+            }
+            Box3 left;
+            uint32_t lcnt = 0;
+            for (int b = 0; b < BINS - 1; b++) {
+                if (bc[b]) left.add(bb[b]);
+                lcnt += bc[b];
+                if (lcnt == 0 || right_cnt[b + 1] == 0) continue;
+                float cost = half_area(left) * (float)lcnt + right_area[b + 1] * (float)right_cnt[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; best_scale = scale; }
+            }
+        }
+        if (best_axis < 0) return lo;
+        const int axis = best_axis, bin = best_bin;
+        const float c0 = cmin[axis], scale = best_scale;
+        auto mid = std::partition(items.begin() + lo, items.begin() + hi, [=](const BuildItem &it) {
+            return std::min(BINS - 1, (int)((it.c[axis] - c0) * scale)) <= bin;
+        });
+        return (size_t)(mid - items.begin());
+    }
 
     // Builds the subtree over items[lo, hi); returns its reference and box.
     uint32_t build(size_t lo, size_t hi, Box3 &box, uint32_t depth) {
@@ -224,13 +297,15 @@ struct Builder {
         max_depth = std::max(max_depth, depth + 1);
         Box3 all;
         for (size_t i = lo; i < hi; i++) all.add(items[i].box);
-        float sx = all.mx[0] - all.mn[0], sy = all.mx[1] - all.mn[1], sz = all.mx[2] - all.mn[2];
-        int axis = sx > sy ? (sx > sz ? 0 : 2) : (sy > sz ? 1 : 2);         // AABB.swift:59-66
-        size_t mid = lo + (hi - lo + 1) / 2;                                  // Hittable.swift:620
-        // Only the split matters (each half is re-ordered on its own axis one level down),
-        // so a selection stands in for the reference's full sort.
-        std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
-                         [axis](const BuildItem &a, const BuildItem &b) { return a.c[axis] < b.c[axis]; });
+        size_t mid = lo;
+        if (sah) {
+            // an unbalanced split is only taken while a balanced subtree below it still
+            // fits the traversal stack
+            uint32_t need = 1;
+            while ((1ull << need) < (hi - lo)) need++;
+            if (depth + 2 + need < RT_STACK_DEPTH) mid = split_sah(lo, hi);
+        }
+        if (mid == lo || mid == hi) mid = split_median(lo, hi, all);
         uint32_t idx = (uint32_t)(nodes.size() / 16);
         nodes.resize(nodes.size() + 16, 0.f);
         Box3 lb, rb;
@@ -642,6 +717,7 @@ int rt_scene_commit(RtScene *sc) {
 
     // ---- BVH over the objects
     Builder bld;
+    bld.sah = sc->bvh_builder == RT_BVH_SAH;
     bld.items.reserve(sc->objects.size() + n_bulk);
     uint32_t feat = 0;
     for (size_t o = 0; o < sc->objects.size(); o++) {
@@ -742,6 +818,23 @@ int rt_scene_commit(RtScene *sc) {
     return RT_OK;
 }
 
+int rt_scene_set_option(RtScene *sc, int option, int value) {
+    if (!sc) return fail(RT_ERR_INVALID, "null scene");
+    switch (option) {
+    case RT_OPTION_BVH_BUILDER:
+        if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
+        if (value != RT_BVH_MEDIAN_SPLIT && value != RT_BVH_SAH) return fail(RT_ERR_INVALID, "unknown BVH builder");
+        sc->bvh_builder = value;
+        return RT_OK;
+    case RT_OPTION_REFILL_THRESHOLD:
+        if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "refill threshold must be 1..64");
+        sc->refill = (uint32_t)value;
+        return RT_OK;
+    default:
+        return fail(RT_ERR_INVALID, "unknown option");
+    }
+}
+
 int rt_scene_stats(const RtScene *sc, RtSceneStats *out) {
     if (!sc || !out) return fail(RT_ERR_INVALID, "null argument");
     if (!sc->committed) return fail(RT_ERR_STATE, "scene not committed");
@@ -799,7 +892,7 @@ int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, i
     hipError_t e;
     if (pipeline == RT_PIPELINE_FUSED) {
         if (workspace_bytes < RT_FUSED_WORKSPACE) return fail(RT_ERR_INVALID, "workspace too small");
-        e = rt_render_fused(sc->dev, sc->feat, cam, r, accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);
+        e = rt_render_fused(sc->dev, sc->feat, cam, r, sc->refill, accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);
     } else if (pipeline == RT_PIPELINE_WAVEFRONT) {
         if (workspace_bytes < rt_wavefront_bytes((uint32_t)width * (uint32_t)height))
             return fail(RT_ERR_INVALID, "workspace too small");

@@ -345,15 +345,24 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_accumulate(const float4 *sample
 }
 
 // ------------------------------------------------------------------ fused persistent kernel
+// Lanes whose traversal has ended wait until at least `refill` (default 48) of them have, then the
+// wave leaves the traversal loop, shades them (which usually starts their next bounce) and
+// hands fresh samples to lanes whose path ended; the others keep their traversal state
+// across the excursion.  Shading therefore runs on a quarter-full wave at worst and
+// traversal never drops below three quarters of the lanes that hold a path.
+
 template <int FEAT>
 __global__ __launch_bounds__(RT_BLOCK) void k_fused(RtDevScene s, RtDevCamera cam, RtDevRender rc, float *accum,
                                                      uint32_t *counter, uint32_t n_items, uint32_t tiles_x,
-                                                     uint32_t n_tiles, uint32_t chunk_spp) {
-    __shared__ uint32_t stack[RT_STACK_DEPTH * RT_BLOCK];
+                                                     uint32_t n_tiles, uint32_t chunk_spp, uint32_t refill) {
+    __shared__ uint32_t stack_mem[RT_STACK_DEPTH * RT_BLOCK];
     __shared__ float tile_acc[RT_WAVES][192];
+    constexpr bool SIMPLE = !(FEAT & RT_FEAT_XPRIM);
     const uint32_t lane = lane_id();
+    uint32_t *stack = stack_mem + threadIdx.x;
     float *acc = tile_acc[threadIdx.x >> 6];
     const uint64_t seed = ((uint64_t)rc.seed_hi << 32) | rc.seed_lo;
+    const float4 *nodes = (const float4 *)s.nodes;
     while (true) {
         uint32_t item = 0;
         if (lane == 0) item = atomicAdd(counter, 1u);
@@ -366,46 +375,69 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fused(RtDevScene s, RtDevCamera ca
         const uint32_t tx0 = (tile % tiles_x) * 8u, ty0 = (tile / tiles_x) * 8u;
         acc[lane] = 0.f; acc[lane + 64] = 0.f; acc[lane + 128] = 0.f;
         uint32_t next = 0;
-        bool alive = false;
-        f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), thr = mk3(0, 0, 0), rad = mk3(0, 0, 0);
+        bool has_path = false;
+        f3 thr = mk3(0, 0, 0), rad = mk3(0, 0, 0);
         uint32_t depth = 0, pix = 0;
+        uint64_t key = 0;
         Pcg g;
         g.state = g.inc = 0;
+        Trav t;
+        trav_begin(t, RT_REF_NONE, mk3(0, 0, 0), mk3(0, 0, 1), RT_INF);
         while (true) {
-            // ---- raygen phase: lanes without a path take the tile's next samples
-            uint64_t need = __ballot(!alive);
-            if (!alive) {
-                uint32_t k = next + prefix_rank(need);
-                if (k < total) {
-                    pix = k & 63u;
-                    uint32_t x = tx0 + (pix & 7u), y = ty0 + (pix >> 3);
-                    if (x < rc.width && y < rc.height) {
-                        g = sample_stream(seed, rc.first_sample + s_begin + (k >> 6), x, y);
-                        camera_ray(cam, x, y, g, o, d);
-                        thr = mk3(1, 1, 1);
-                        rad = mk3(0, 0, 0);
-                        depth = 0;
-                        alive = true;
-                    }
-                }
-            }
-            next += (uint32_t)__popcll(need);
-            if (!__any(alive)) {
-                if (next >= total) break;
-                continue;
-            }
-            // ---- extend + shade phases
-            if (alive) {
-                Best b;
-                bool found = trace<!(FEAT & RT_FEAT_XPRIM)>(s, o, d, RT_T_MIN, RT_INF, g.state, nullptr, 0,
-                                                           stack + threadIdx.x, b);
-                alive = shade_path<FEAT>(s, cam.background, rc.max_depth, found, b, o, d, thr, rad, depth, g);
-                if (!alive) {
-                    // ---- accumulate phase (LDS atomics: lanes of the wave may share a pixel)
+            // ---- shade phase: lanes whose traversal ended
+            bool start = false;
+            f3 o = t.o, d = t.d;
+            if (has_path && t.cur == RT_REF_NONE) {
+                bool alive = shade_path<FEAT>(s, cam.background, rc.max_depth, t.found, t.best, o, d, thr, rad, depth, g);
+                if (alive) {
+                    start = true;
+                } else {
+                    // accumulate phase (LDS atomics: lanes of the wave may share a pixel)
                     atomicAdd(&acc[3u * pix + 0u], rad.x);
                     atomicAdd(&acc[3u * pix + 1u], rad.y);
                     atomicAdd(&acc[3u * pix + 2u], rad.z);
+                    has_path = false;
                 }
+            }
+            // ---- raygen phase: lanes without a path take the tile's next samples
+            if (next < total) {
+                uint64_t need = __ballot(!has_path);
+                if (!has_path) {
+                    uint32_t k = next + prefix_rank(need);
+                    if (k < total) {
+                        pix = k & 63u;
+                        uint32_t x = tx0 + (pix & 7u), y = ty0 + (pix >> 3);
+                        if (x < rc.width && y < rc.height) {
+                            g = sample_stream(seed, rc.first_sample + s_begin + (k >> 6), x, y);
+                            camera_ray(cam, x, y, g, o, d);
+                            thr = mk3(1, 1, 1);
+                            rad = mk3(0, 0, 0);
+                            depth = 0;
+                            has_path = true;
+                            start = true;
+                        }
+                    }
+                }
+                next += (uint32_t)__popcll(need);
+            }
+            if (start) {
+                key = g.state;
+                trav_begin(t, s.root, o, d, RT_INF);
+            }
+            const uint32_t n_paths = (uint32_t)__popcll(__ballot(has_path));
+            if (n_paths == 0) {
+                if (next >= total) break;
+                continue;
+            }
+            // ---- extend phase
+            while (true) {
+                while (!(t.cur & RT_REF_LEAF)) trav_node(nodes, t, RT_T_MIN, stack);
+                if (t.cur != RT_REF_NONE) {
+                    test_object<SIMPLE>(s, t.cur & ~RT_REF_LEAF, t.o, t.d, RT_T_MIN, RT_INF, key, nullptr, 0, t.found, t.best);
+                    trav_pop(t, stack);
+                }
+                uint32_t n_active = (uint32_t)__popcll(__ballot(t.cur != RT_REF_NONE));
+                if (n_active == 0 || n_paths - n_active >= refill) break;
             }
         }
         // flush the tile (other chunks of the same tile may be in flight elsewhere)
@@ -542,7 +574,7 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
 
 template <int FEAT>
 static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, const RtDevRender &rc, float *accum,
-                               uint32_t *counter, hipStream_t stream, RtKernelTimer *timer) {
+                               uint32_t *counter, uint32_t refill, hipStream_t stream, RtKernelTimer *timer) {
     uint32_t tiles_x = (rc.width + 7u) / 8u, tiles_y = (rc.height + 7u) / 8u, n_tiles = tiles_x * tiles_y;
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
@@ -557,21 +589,21 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     hipError_t e = hipMemsetAsync(counter, 0, 256, stream);
     if (e != hipSuccess) return e;
     if (timer) timer->begin(stream);
-    k_fused<FEAT><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp);
+    k_fused<FEAT><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, refill);
     if (timer) timer->end(stream);
     return hipGetLastError();
 }
 
-hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc, float *accum,
+hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc, uint32_t refill, float *accum,
                            void *workspace, size_t workspace_bytes, hipStream_t stream, RtKernelTimer *timer) {
     if (rc.width == 0 || rc.height == 0 || rc.spp == 0) return hipSuccess;
     if (workspace_bytes < RT_FUSED_WORKSPACE) return hipErrorInvalidValue;
     if (timer) timer->name = "k_fused";
     uint32_t *counter = (uint32_t *)workspace;
     switch (feat & 3u) {
-    case 0: return fused_launch<0>(s, cam, rc, accum, counter, stream, timer);
-    case 1: return fused_launch<1>(s, cam, rc, accum, counter, stream, timer);
-    case 2: return fused_launch<2>(s, cam, rc, accum, counter, stream, timer);
-    default: return fused_launch<3>(s, cam, rc, accum, counter, stream, timer);
+    case 0: return fused_launch<0>(s, cam, rc, accum, counter, refill, stream, timer);
+    case 1: return fused_launch<1>(s, cam, rc, accum, counter, refill, stream, timer);
+    case 2: return fused_launch<2>(s, cam, rc, accum, counter, refill, stream, timer);
+    default: return fused_launch<3>(s, cam, rc, accum, counter, refill, stream, timer);
     }
 }

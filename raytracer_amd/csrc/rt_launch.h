@@ -82,7 +82,7 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
                                float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
                                RtKernelTimer *timer);
 hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc,
-                           float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
+                           uint32_t refill, float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
                            RtKernelTimer *timer);
 
 #define RT_WAVEFRONT_BATCH_SPP 8u      // samples per pixel resident in the path queues at once

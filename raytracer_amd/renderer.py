@@ -92,6 +92,9 @@ class NativeScene:
         m = np.ascontiguousarray(mat_ids, dtype=np.uint32)
         return check(lib.rt_add_sphere_objects(self.h, len(m), cr.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p)))
 
+    def set_option(self, option, value):
+        check(lib.rt_scene_set_option(self.h, option, value))
+
     def commit(self):
         check(lib.rt_scene_commit(self.h))
         self.committed = True
@@ -150,12 +153,16 @@ class Renderer:
     """ContentView.swift:103-235.  `draw` = one pass of `samples_per_pixel` samples added to
     the float accumulator; the accumulator resets when the size changes (:172-180)."""
 
-    def __init__(self, scene, width, height, pipeline=abi.RT_PIPELINE_FUSED, device_ordinal=0, ctx=None, dedup=True):
+    def __init__(self, scene, width, height, pipeline=abi.RT_PIPELINE_FUSED, device_ordinal=0, ctx=None, dedup=True,
+                 bvh=abi.RT_BVH_SAH, refill=None):
         self.ctx = ctx or Context(device_ordinal)
         self.scene = scene
         self.camera = scene.camera
         self.native = NativeScene(self.ctx)
         scene.encode(self.native, dedup=dedup)
+        self.native.set_option(abi.RT_OPTION_BVH_BUILDER, bvh)
+        if refill:
+            self.native.set_option(abi.RT_OPTION_REFILL_THRESHOLD, refill)
         self.native.commit()
         self.pipeline = pipeline
         self.pass_counter = 0
