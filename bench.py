@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bvh", default="sah", choices=["sah", "median"])
     ap.add_argument("--refill", type=int, default=0)
+    ap.add_argument("--node-min", type=int, default=-1)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,7 +88,7 @@ def main():
         spp = args.spp
     pipeline = abi.RT_PIPELINE_FUSED if args.pipeline == "fused" else abi.RT_PIPELINE_WAVEFRONT
     r = Renderer(scene, w, h, pipeline=pipeline, device_ordinal=local_rank,
-                 bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_MEDIAN_SPLIT, refill=args.refill or None)
+                 bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_MEDIAN_SPLIT, refill=args.refill or None, node_min=None if args.node_min < 0 else args.node_min)
 
     def step(i):
         # rank g renders sample indices [ (i*world + g)*spp, +spp ): disjoint over ranks and steps

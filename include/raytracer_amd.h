@@ -225,8 +225,9 @@ int rt_scene_stats(const RtScene *, RtSceneStats *out);
  * RT_OPTION_BVH_BUILDER (before commit): RT_BVH_MEDIAN_SPLIT is the reference's rule
  * (RayTracingKit/Hittable.swift:609-631), RT_BVH_SAH (default) a binned surface-area
  * heuristic; hit results do not depend on the choice.  RT_OPTION_REFILL_THRESHOLD: how many
- * lanes of a wave must be waiting before the fused kernel leaves its traversal loop. */
-enum RtOption { RT_OPTION_BVH_BUILDER = 1, RT_OPTION_REFILL_THRESHOLD = 2 };
+ * lanes of a wave must be waiting before the fused kernel leaves its traversal loop.
+ * RT_OPTION_NODE_MIN: below how many lanes on inner nodes the kernel turns to waiting leaf tests. */
+enum RtOption { RT_OPTION_BVH_BUILDER = 1, RT_OPTION_REFILL_THRESHOLD = 2, RT_OPTION_NODE_MIN = 3 };
 enum RtBvhBuilder { RT_BVH_MEDIAN_SPLIT = 0, RT_BVH_SAH = 1 };
 int rt_scene_set_option(RtScene *, int option, int value);
 

@@ -7,7 +7,7 @@ import os
 from . import abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libraytracer_amd.so")
+LIB_PATH = os.environ.get("RT_LIB") or os.path.join(HERE, "lib", "libraytracer_amd.so")   # RT_LIB: A/B builds
 
 # every symbol include/raytracer_amd.h declares
 EXPORTS = [

@@ -704,9 +704,12 @@ RT_DEV void complete_hit(const RtDevScene &s, const Best &best, f3 o, f3 d, bool
 // ------------------------------------------------------------------ materials (shade)
 // Material record: 8 floats = kind, texture id, fuzz, refraction index, albedo rgb, pad.
 struct Material { uint32_t kind, texture; float fuzz, ior; f3 albedo; };
+RT_DEV Material unpack_material(float4 a, float4 b);
 RT_DEV Material load_material(const RtDevScene &s, uint32_t id) {
     const float4 *q = (const float4 *)s.materials + 2u * id;
-    float4 a = q[0], b = q[1];
+    return unpack_material(q[0], q[1]);
+}
+RT_DEV Material unpack_material(float4 a, float4 b) {
     Material m;
     m.kind = __float_as_uint(a.x);
     m.texture = __float_as_uint(a.y);
@@ -792,19 +795,24 @@ RT_DEV bool scatter(const RtDevScene &s, const Material &m, f3 d, const HitRecor
                     f3 &emitted, f3 &attenuation, f3 &new_d) {
     emitted = mk3(0, 0, 0);
     attenuation = mk3(0, 0, 0);
+    // lambertian, metal and isotropic all start by drawing one unit vector: drawn once
+    // here, so that a wave holding a mix of them runs the rejection loop once
+    f3 rv = mk3(0, 0, 0);
+    if (m.kind != 7u && m.kind != 8u) rv = random_unit_vector_3d(g);
     switch (m.kind) {
     case 1: case 2: case 3: {      // lambertian
         while (true) {
-            f3 v = h.normal + random_unit_vector_3d(g);
+            f3 v = h.normal + rv;
             float len_sq = dot(v, v);
             if (len_sq > RT_MIN_LEN_SQ) { new_d = v * __builtin_amdgcn_rsqf(len_sq); break; }
+            rv = random_unit_vector_3d(g);
         }
         attenuation = material_color(s, m, h);
         return true;
     }
     case 4: case 5: case 6: {      // metal
         f3 refl = madd(h.normal, -2.0f * dot(d, h.normal), d);
-        refl = madd(random_unit_vector_3d(g), m.fuzz, refl);
+        refl = madd(rv, m.fuzz, refl);
         if (dot(refl, h.normal) < 0.0f) return false;
         attenuation = material_color(s, m, h);
         new_d = normalize3(refl);
@@ -826,7 +834,7 @@ RT_DEV bool scatter(const RtDevScene &s, const Material &m, f3 d, const HitRecor
         emitted = m.albedo;
         return false;
     default:                       // isotropic
-        new_d = random_unit_vector_3d(g);
+        new_d = rv;
         attenuation = m.albedo;
         return true;
     }

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -76,7 +77,7 @@ struct RtScene {
     std::vector<float> bulk_spheres;       // cx, cy, cz, r
     std::vector<uint32_t> bulk_mats;
     int bvh_builder = RT_BVH_SAH;
-    uint32_t refill = 48;
+    uint32_t refill = 48, node_min = 32;
     bool committed = false;
     std::vector<void *> device_allocs;
     RtDevScene dev{};
@@ -783,6 +784,11 @@ int rt_scene_commit(RtScene *sc) {
     if ((rc = upload(sc, spheres, &d.spheres)) < 0) return rc;
     if ((rc = upload(sc, sphere_rot, &d.sphere_rot)) < 0) return rc;
     if ((rc = upload(sc, sphere_mat, &d.sphere_mat)) < 0) return rc;
+    {
+        std::vector<float> mrec(sphere_mat.size() * 8);
+        for (size_t i = 0; i < sphere_mat.size(); i++) memcpy(mrec.data() + 8 * i, sc->materials.data() + 8 * (size_t)sphere_mat[i], 32);
+        if ((rc = upload(sc, mrec, &d.sphere_mrec)) < 0) return rc;
+    }
     if ((rc = upload(sc, sphere_obj, &d.sphere_obj)) < 0) return rc;
     if ((rc = upload(sc, xprims, &d.xprims)) < 0) return rc;
     if ((rc = upload(sc, xprim_mat, &d.xprim_mat)) < 0) return rc;
@@ -829,6 +835,10 @@ int rt_scene_set_option(RtScene *sc, int option, int value) {
     case RT_OPTION_REFILL_THRESHOLD:
         if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "refill threshold must be 1..64");
         sc->refill = (uint32_t)value;
+        return RT_OK;
+    case RT_OPTION_NODE_MIN:
+        if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "node minimum must be 0..64");
+        sc->node_min = (uint32_t)value;
         return RT_OK;
     default:
         return fail(RT_ERR_INVALID, "unknown option");
@@ -892,7 +902,7 @@ int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, i
     hipError_t e;
     if (pipeline == RT_PIPELINE_FUSED) {
         if (workspace_bytes < RT_FUSED_WORKSPACE) return fail(RT_ERR_INVALID, "workspace too small");
-        e = rt_render_fused(sc->dev, sc->feat, cam, r, sc->refill, accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);
+        e = rt_render_fused(sc->dev, sc->feat, cam, r, sc->refill | (sc->node_min << 8) | (getenv("RT_PROFILE_PHASES") ? 0x10000u : 0u), accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);
     } else if (pipeline == RT_PIPELINE_WAVEFRONT) {
         if (workspace_bytes < rt_wavefront_bytes((uint32_t)width * (uint32_t)height))
             return fail(RT_ERR_INVALID, "workspace too small");

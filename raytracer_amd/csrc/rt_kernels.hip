@@ -204,26 +204,29 @@ RT_DEV bool shade_path(const RtDevScene &s, uint32_t background, uint32_t max_de
     HitRecord h;
     uint32_t kind = (b.ref >> RT_KIND_SHIFT) & 7u;
     bool maybe_uv = (FEAT & RT_FEAT_TEXTURE) != 0;
+    Material m;
     if (!(FEAT & RT_FEAT_XPRIM)) {
-        // spheres only: skip the generic completion
+        // spheres only: geometry and the sphere's own copy of its material record are
+        // independent loads (one memory round trip)
         uint32_t idx = b.ref & RT_INDEX_MASK;
-        Surface sf = prim_surface(s, b.ref, 0, o, d, b.t, false);
+        float4 g4 = ((const float4 *)s.spheres)[idx];
+        const float4 *mr = (const float4 *)s.sphere_mrec + 2u * idx;
+        float4 m0 = mr[0], m1 = mr[1];
+        m = unpack_material(m0, m1);
         h.point = madd(d, b.t, o);
-        h.material = sf.material;
+        f3 n = (h.point - mk3(g4.x, g4.y, g4.z)) * rcp(g4.w);
+        h.material = 0;
         h.u = h.v = 0.f;
-        if (dot(sf.normal, d) > 0.f) { h.normal = -sf.normal; h.front = false; } else { h.normal = sf.normal; h.front = true; }
-        (void)idx; (void)kind;
-        if (maybe_uv) {
-            Material mm = load_material(s, h.material);
-            if (material_wants_uv(mm.kind)) {
-                sf = prim_surface(s, b.ref, 0, o, d, b.t, true);
-                h.u = sf.u; h.v = sf.v;
-            }
+        if (dot(n, d) > 0.f) { h.normal = -n; h.front = false; } else { h.normal = n; h.front = true; }
+        (void)kind;
+        if (maybe_uv && material_wants_uv(m.kind)) {
+            Surface sf = prim_surface(s, b.ref, 0, o, d, b.t, true);
+            h.u = sf.u; h.v = sf.v;
         }
     } else {
         complete_hit(s, b, o, d, maybe_uv, h);
+        m = load_material(s, h.material);
     }
-    Material m = load_material(s, h.material);
     f3 emitted, atten, nd;
     bool did = scatter(s, m, d, h, g, emitted, atten, nd);
     rad = rad + thr * emitted;
@@ -351,18 +354,29 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_accumulate(const float4 *sample
 // across the excursion.  Shading therefore runs on a quarter-full wave at worst and
 // traversal never drops below three quarters of the lanes that hold a path.
 
-template <int FEAT>
-__global__ __launch_bounds__(RT_BLOCK) void k_fused(RtDevScene s, RtDevCamera cam, RtDevRender rc, float *accum,
+// PROF = true is a diagnostic build: it counts, per phase, wave-level executions, the lanes
+// that took part, and shader cycles, into 16 words behind the work counter.  Its run time
+// means nothing (the stamps serialise the phases).
+#ifndef RT_FUSED_WPS
+#define RT_FUSED_WPS 4      // waves per SIMD the register allocation of k_fused is bounded for
+#endif
+template <int FEAT, bool PROF>
+__global__ __launch_bounds__(RT_BLOCK, RT_FUSED_WPS) void k_fused(RtDevScene s, RtDevCamera cam, RtDevRender rc, float *accum,
                                                      uint32_t *counter, uint32_t n_items, uint32_t tiles_x,
-                                                     uint32_t n_tiles, uint32_t chunk_spp, uint32_t refill) {
+                                                     uint32_t n_tiles, uint32_t chunk_spp, uint32_t knobs) {
     __shared__ uint32_t stack_mem[RT_STACK_DEPTH * RT_BLOCK];
     __shared__ float tile_acc[RT_WAVES][192];
     constexpr bool SIMPLE = !(FEAT & RT_FEAT_XPRIM);
+    const uint32_t refill = knobs & 255u, node_min = (knobs >> 8) & 255u;
     const uint32_t lane = lane_id();
     uint32_t *stack = stack_mem + threadIdx.x;
     float *acc = tile_acc[threadIdx.x >> 6];
     const uint64_t seed = ((uint64_t)rc.seed_hi << 32) | rc.seed_lo;
     const float4 *nodes = (const float4 *)s.nodes;
+    unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // {execs, lanes, cycles} x {shade, raygen, node, leaf}
+    unsigned long long stamp = 0;
+#define RT_PROF_BEGIN() do { if (PROF) stamp = __builtin_amdgcn_s_memtime(); } while (0)
+#define RT_PROF_END(k, cond) do { if (PROF) { unsigned long long m_ = __ballot(cond); if (m_) { pc[3 * (k)] += 1; pc[3 * (k) + 1] += __popcll(m_); pc[3 * (k) + 2] += __builtin_amdgcn_s_memtime() - stamp; } } } while (0)
     while (true) {
         uint32_t item = 0;
         if (lane == 0) item = atomicAdd(counter, 1u);
@@ -387,6 +401,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fused(RtDevScene s, RtDevCamera ca
             // ---- shade phase: lanes whose traversal ended
             bool start = false;
             f3 o = t.o, d = t.d;
+            RT_PROF_BEGIN();
+            const bool shading = has_path && t.cur == RT_REF_NONE;
             if (has_path && t.cur == RT_REF_NONE) {
                 bool alive = shade_path<FEAT>(s, cam.background, rc.max_depth, t.found, t.best, o, d, thr, rad, depth, g);
                 if (alive) {
@@ -399,6 +415,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fused(RtDevScene s, RtDevCamera ca
                     has_path = false;
                 }
             }
+            RT_PROF_END(0, shading);
+            RT_PROF_BEGIN();
+            const bool generating = !has_path && next < total;
             // ---- raygen phase: lanes without a path take the tile's next samples
             if (next < total) {
                 uint64_t need = __ballot(!has_path);
@@ -420,6 +439,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fused(RtDevScene s, RtDevCamera ca
                 }
                 next += (uint32_t)__popcll(need);
             }
+            RT_PROF_END(1, generating);
             if (start) {
                 key = g.state;
                 trav_begin(t, s.root, o, d, RT_INF);
@@ -431,11 +451,24 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fused(RtDevScene s, RtDevCamera ca
             }
             // ---- extend phase
             while (true) {
-                while (!(t.cur & RT_REF_LEAF)) trav_node(nodes, t, RT_T_MIN, stack);
-                if (t.cur != RT_REF_NONE) {
+                // node steps go on while enough lanes sit on inner nodes; once fewer than
+                // node_min do and some lane waits at a leaf, the leaf tests get their turn
+                while (true) {
+                    bool inner = !(t.cur & RT_REF_LEAF);
+                    uint32_t n_inner = (uint32_t)__popcll(__ballot(inner));
+                    if (n_inner == 0) break;
+                    if (n_inner < node_min && __ballot(!inner && t.cur != RT_REF_NONE)) break;
+                    RT_PROF_BEGIN();
+                    if (inner) trav_node(nodes, t, RT_T_MIN, stack);
+                    RT_PROF_END(2, inner);
+                }
+                RT_PROF_BEGIN();
+                const bool at_leaf = (t.cur & RT_REF_LEAF) && t.cur != RT_REF_NONE;
+                if (at_leaf) {
                     test_object<SIMPLE>(s, t.cur & ~RT_REF_LEAF, t.o, t.d, RT_T_MIN, RT_INF, key, nullptr, 0, t.found, t.best);
                     trav_pop(t, stack);
                 }
+                RT_PROF_END(3, at_leaf);
                 uint32_t n_active = (uint32_t)__popcll(__ballot(t.cur != RT_REF_NONE));
                 if (n_active == 0 || n_paths - n_active >= refill) break;
             }
@@ -451,6 +484,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fused(RtDevScene s, RtDevCamera ca
             }
         }
     }
+    if (PROF && lane == 0) {
+        unsigned long long *out = (unsigned long long *)(counter + 64);
+        for (int k = 0; k < 12; k++) atomicAdd(out + k, pc[k]);
+    }
+#undef RT_PROF_BEGIN
+#undef RT_PROF_END
 }
 
 // ------------------------------------------------------------------ launchers
@@ -577,7 +616,7 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
                                uint32_t *counter, uint32_t refill, hipStream_t stream, RtKernelTimer *timer) {
     uint32_t tiles_x = (rc.width + 7u) / 8u, tiles_y = (rc.height + 7u) / 8u, n_tiles = tiles_x * tiles_y;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
     int grid = device_cus() * occ;
     // enough work items that the dynamic queue evens out the waves: >= 8 per resident wave
     uint32_t want_items = (uint32_t)grid * RT_WAVES * 8u;
@@ -586,10 +625,13 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     n_chunks = (rc.spp + chunk_spp - 1u) / chunk_spp;
     uint32_t n_items = n_tiles * n_chunks;
     grid = (int)std::min<uint32_t>((uint32_t)grid, (n_items + RT_WAVES - 1u) / RT_WAVES);
-    hipError_t e = hipMemsetAsync(counter, 0, 256, stream);
+    hipError_t e = hipMemsetAsync(counter, 0, (refill & 0x10000u) ? 512 : 256, stream);
     if (e != hipSuccess) return e;
     if (timer) timer->begin(stream);
-    k_fused<FEAT><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, refill);
+    if (refill & 0x10000u)
+        k_fused<FEAT, true><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, refill);
+    else
+        k_fused<FEAT, false><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, refill);
     if (timer) timer->end(stream);
     return hipGetLastError();
 }

@@ -29,7 +29,9 @@ enum RtPrimKind : uint32_t {
     RT_KIND_CDV = 5,
 };
 
+#ifndef RT_STACK_DEPTH
 #define RT_STACK_DEPTH 32        // traversal stack entries per lane (LDS)
+#endif
 #define RT_BLOCK 256             // threads per workgroup of every traversal kernel
 #define RT_CSG_LEAVES 8
 
@@ -66,6 +68,7 @@ struct RtDevScene {
     const float *spheres;          // n x 4
     const float *sphere_rot;       // n x 12 (three padded columns) or nullptr when every rotation is identity
     const uint32_t *sphere_mat;
+    const float *sphere_mrec;      // n x 8: the material record of each sphere, by value (shade needs no second lookup)
     const uint32_t *sphere_obj;
     const float *xprims;           // n x 16
     const uint32_t *xprim_mat;     // n x 6

@@ -154,7 +154,7 @@ class Renderer:
     the float accumulator; the accumulator resets when the size changes (:172-180)."""
 
     def __init__(self, scene, width, height, pipeline=abi.RT_PIPELINE_FUSED, device_ordinal=0, ctx=None, dedup=True,
-                 bvh=abi.RT_BVH_SAH, refill=None):
+                 bvh=abi.RT_BVH_SAH, refill=None, node_min=None):
         self.ctx = ctx or Context(device_ordinal)
         self.scene = scene
         self.camera = scene.camera
@@ -163,6 +163,8 @@ class Renderer:
         self.native.set_option(abi.RT_OPTION_BVH_BUILDER, bvh)
         if refill:
             self.native.set_option(abi.RT_OPTION_REFILL_THRESHOLD, refill)
+        if node_min is not None:
+            self.native.set_option(abi.RT_OPTION_NODE_MIN, node_min)
         self.native.commit()
         self.pipeline = pipeline
         self.pass_counter = 0
