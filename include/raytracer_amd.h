@@ -186,6 +186,7 @@ int rt_abi_version(void);
 
 /* ---- scene description: replaces SceneBuffers.init (SceneBuffers.swift:15-72) -- */
 
+/* ctx may be NULL for a description-only scene (validated, but rt_scene_commit fails). */
 int rt_scene_create(RtContext *, RtScene **out);
 void rt_scene_destroy(RtScene *);
 

@@ -555,7 +555,13 @@ struct Trav {
 
 RT_DEV void trav_begin(Trav &t, uint32_t root, f3 o, f3 d, float tmax) {
     t.o = o; t.d = d;
-    t.inv_d = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
+    // A zero direction component would make plane*(1/d) - o*(1/d) an inf - inf; a component
+    // of magnitude 2^-80 instead keeps the product form exact in sign and still puts
+    // the slab planes ~1e24 units away.
+    const float tiny = 8.271806e-25f;
+    f3 ds = mk3(fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x), fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y),
+                fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
+    t.inv_d = mk3(rcp(ds.x), rcp(ds.y), rcp(ds.z));
     t.oid = mk3(-o.x * t.inv_d.x, -o.y * t.inv_d.y, -o.z * t.inv_d.z);
     t.cur = root;
     t.sp = 0;

@@ -405,7 +405,9 @@ int rt_context_create(int device_ordinal, RtContext **out) {
 void rt_context_destroy(RtContext *c) { delete c; }
 
 int rt_scene_create(RtContext *ctx, RtScene **out) {
-    if (!ctx || !out) return fail(RT_ERR_INVALID, "null argument");
+    if (!out) return fail(RT_ERR_INVALID, "null argument");
+    // A null context gives a description-only scene: everything up to rt_scene_commit works
+    // (and is validated) without a device.
     RtScene *s = new RtScene();
     s->ctx = ctx;
     *out = s;
@@ -624,6 +626,7 @@ int rt_add_sphere_objects(RtScene *sc, int n, const float *center_radius, const 
 int rt_scene_commit(RtScene *sc) {
     if (!sc) return fail(RT_ERR_INVALID, "null scene");
     if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
+    if (!sc->ctx) return fail(RT_ERR_STATE, "scene was created without a device context");
     hipError_t he = hipSetDevice(sc->ctx->device);
     if (he != hipSuccess) return fail_hip(he, "hipSetDevice");
     sc->stats = RtSceneStats{};

@@ -106,3 +106,53 @@ def test_quad_record_follows_reference_formulas():
     Quad((1, 2, 3), (2, 0, 0), (0, 3, 0), ColoredLambertian((1, 1, 1))).as_impl(SceneEncoder(s))
     assert np.allclose(list(s.rec.normal), [0, 0, 1]) and abs(s.rec.d - 3) < 1e-6
     assert np.allclose(list(s.rec.w), [0, 0, 1 / 6.0])
+
+
+def _host_scene():
+    from raytracer_amd._native import lib
+    h = C.c_void_p()
+    assert lib.rt_scene_create(None, C.byref(h)) == 0
+    return lib, h
+
+
+def test_description_limits_and_errors_without_a_gpu():
+    """What the reference answers with a crash at pipeline creation
+    (ContentView.swift:136-138) comes back as an error code here."""
+    lib, h = _host_scene()
+    mat = abi.RtColoredLambertianMaterial(abi.material_kind_lambertian_colored, abi.F3(.5, .5, .5))
+    assert lib.rt_add_material(h, C.byref(mat), C.sizeof(mat)) == 0
+    assert lib.rt_add_material(h, C.byref(mat), 7) < 0                     # size does not match the kind
+    bad = abi.RtColoredLambertianMaterial(77, abi.F3(0, 0, 0))
+    assert lib.rt_add_material(h, C.byref(bad), C.sizeof(bad)) < 0
+    tex = abi.RtTexturedLambertianMaterial(abi.material_kind_lambertian_textured, abi.RtImageTexture(3))
+    assert lib.rt_add_material(h, C.byref(tex), C.sizeof(tex)) < 0         # no such texture
+    sph = abi.RtSphere()
+    sph.transform.rotation = (C.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
+    sph.radius = 1.0
+    sph.material_offset = 5
+    assert lib.rt_shape_sphere(h, C.byref(sph)) < 0 and b"material" in lib.rt_last_error()
+    sph.material_offset = 0
+    ids = [lib.rt_shape_sphere(h, C.byref(sph)) for _ in range(10)]
+    assert ids == list(range(10))
+    arr9 = (C.c_int * 9)(*ids[:9])
+    assert lib.rt_shape_csg(h, abi.RT_CSG_UNION, 9, arr9) == -3            # RT_ERR_LIMIT: more than 8 leaves
+    arr8 = (C.c_int * 8)(*ids[:8])
+    u = lib.rt_shape_csg(h, abi.RT_CSG_UNION, 8, arr8)
+    assert u == 10
+    assert lib.rt_shape_csg(h, abi.RT_CSG_UNION, 8, arr8) < 0              # children already in use
+    assert lib.rt_add_object(h, ids[0]) < 0                                # a CSG child is not an object
+    fog = lib.rt_shape_cdv(h, ids[8], 0.5)
+    assert fog == 11
+    assert lib.rt_shape_cdv(h, fog, 0.5) < 0                               # volume of a volume
+    two = (C.c_int * 2)(ids[9], fog)
+    assert lib.rt_shape_csg(h, abi.RT_CSG_SUBTRACT, 2, two) < 0            # volume as a CSG operand
+    assert lib.rt_shape_cdv(h, ids[9], 0.0) < 0                            # density must be positive
+    assert lib.rt_add_object(h, u) == 0 and lib.rt_add_object(h, fog) == 1
+    assert lib.rt_add_object(h, u) < 0                                     # twice
+    assert lib.rt_scene_set_option(h, abi.RT_OPTION_BVH_BUILDER, 7) < 0
+    assert lib.rt_scene_set_option(h, abi.RT_OPTION_BVH_BUILDER, abi.RT_BVH_MEDIAN_SPLIT) == 0
+    assert lib.rt_scene_commit(h) == -2 and b"context" in lib.rt_last_error()   # RT_ERR_STATE: no device
+    st = abi.RtSceneStats()
+    assert lib.rt_scene_stats(h, C.byref(st)) == -2
+    assert lib.rt_first_hit(h, None, 0, 0.0, 1.0, 0, None, None) == -2
+    lib.rt_scene_destroy(h)

@@ -1,0 +1,214 @@
+"""Edge cases of the HIP path against the CPU oracle (GPU needed): empty and tiny scenes,
+axis-parallel rays, both BVH builders, every CSG operator incl. volumes over CSG shapes and
+half-space quads, a 100k-sphere cloud through the bulk entry point, full-size properties."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_bridge as ob
+from common import random_rays
+from raytracer_amd import abi, scenes
+from raytracer_amd.scene import (CameraConfig, ColoredLambertian, ConstantDensityVolume, Cuboid, Cylinder, Intersection,
+                                 Quad, RenderConfig, Scene, SceneEncoder, Sphere, Subtract, Transform, Union,
+                                 ColoredIsotropic)
+from test_gpu_parity import compare_first_hits
+
+pytestmark = pytest.mark.gpu
+T = Transform
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from raytracer_amd.renderer import Context
+    return Context(0)
+
+
+def both(ctx, scene, bvh=abi.RT_BVH_SAH):
+    from raytracer_amd.renderer import NativeScene
+    nat = NativeScene(ctx)
+    scene.encode(nat)
+    nat.set_option(abi.RT_OPTION_BVH_BUILDER, bvh)
+    nat.commit()
+    return nat, ob.oracle_scene_from(scene)
+
+
+def test_empty_scene_renders_background(ctx):
+    from raytracer_amd.renderer import Renderer
+    scene = Scene(CameraConfig(), [])
+    for pipeline in (abi.RT_PIPELINE_WAVEFRONT, abi.RT_PIPELINE_FUSED):
+        r = Renderer(scene, 32, 16, pipeline=pipeline, ctx=ctx)
+        r.draw(2, 5, 1)
+        torch.cuda.synchronize()
+        img = r.mean().cpu().numpy()
+        assert np.isfinite(img).all() and img.min() > 0.2       # sky everywhere
+    orc = ob.oracle_scene_from(scene)
+    ref, _, _ = orc.render(scene.camera, RenderConfig(2, 5, 1, 1, 0), 32, 16)
+    assert np.abs(img - ref / 2).max() < 1e-5
+    hits = r.native.first_hit(random_rays(64, 1))
+    assert (hits["object"] == -1).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5])
+def test_tiny_scenes(ctx, n):
+    m = ColoredLambertian((0.5, 0.5, 0.5))
+    objs = [Sphere((1.5 * i - 2, 0.1 * i, 0.3 * i), 0.6, m) for i in range(n)]
+    scene = Scene(CameraConfig(look_from=(0, 0, 6), look_at=(0, 0, 0)), objs)
+    rays = random_rays(3000, n, radius=6.0, aim_radius=2.5)
+    for bvh in (abi.RT_BVH_SAH, abi.RT_BVH_MEDIAN_SPLIT):
+        nat, orc = both(ctx, scene, bvh)
+        compare_first_hits(nat.first_hit(rays), orc.first_hit(rays), rays, scene, what="tiny%d" % n)
+
+
+def test_axis_parallel_rays_on_every_primitive(ctx):
+    """Zero direction components: the slab / cap branches with infinite distances
+    (RenderableImpl.h:128-138, 190-200, 297-307)."""
+    m = ColoredLambertian((0.5, 0.5, 0.5))
+    scene = Scene(CameraConfig(), [
+        Cuboid(T.translate(-3, -1, -1), (2, 2, 2), m),
+        Cylinder(T.translate(0, -1, 0), 0.8, 2.0, m),
+        Sphere((3, 0, 0), 1.0, m),
+        Quad((-1, -1, -3), (2, 0, 0), (0, 2, 0), m),
+        Cylinder(T.translate(0, 3, 0) * T.rotation_deg(90, "z"), 0.5, 3.0, m),
+    ])
+    rs = np.random.RandomState(4)
+    rays = []
+    for axis in range(3):
+        for sign in (-1.0, 1.0):
+            o = rs.uniform(-4, 4, size=(800, 3))
+            o[:, axis] = -sign * 8
+            d = np.zeros((800, 3))
+            d[:, axis] = sign
+            rays.append(np.concatenate([o, d], axis=1))
+    # origins exactly on slab planes and inside the shapes
+    o = np.array([[-3, 0, 0], [-1, 0, 0], [0, -1, 0], [0, 1, 0], [0, 0, 0], [3, 0, 0], [-2, 0, 0]], dtype=float)
+    for axis in range(3):
+        d = np.zeros((len(o), 3)); d[:, axis] = 1
+        rays.append(np.concatenate([o, d], axis=1))
+    rays = np.concatenate(rays).astype(np.float32)
+    nat, orc = both(ctx, scene)
+    compare_first_hits(nat.first_hit(rays), orc.first_hit(rays), rays, scene, what="axis-parallel", max_bad_frac=1e-3)
+
+
+def test_bvh_builders_give_identical_hits(ctx):
+    scene = scenes.csg_textured(7)
+    rays = random_rays(20000, 9, center=(0, 0, -2), radius=12.0, aim_radius=8.0)
+    a, _ = both(ctx, scene, abi.RT_BVH_SAH)
+    from raytracer_amd.renderer import NativeScene
+    b = NativeScene(ctx)
+    scene.encode(b)
+    b.set_option(abi.RT_OPTION_BVH_BUILDER, abi.RT_BVH_MEDIAN_SPLIT)
+    b.commit()
+    ha, hb = a.first_hit(rays), b.first_hit(rays)
+    same = (ha["object"] == hb["object"])
+    assert same.mean() > 0.9999        # only exact ties between two objects may differ
+    assert np.array_equal(ha["t"][same], hb["t"][same])
+    assert b.stats()["bvh_depth"] <= 8 and a.stats()["n_nodes"] == b.stats()["n_nodes"]
+
+
+def _interval_mismatches(nat, sid, orc, oid, rays, scripted=None, key=0):
+    got = nat.intervals(sid, rays, scripted=scripted, volume_key=key)
+    bad = 0
+    for i in range(len(rays)):
+        ref = orc.enumerate(oid, rays[i, :3], rays[i, 3:], precision=ob.ORC_F64, scripted=scripted)
+        ev = got[i]
+        ok = len(ev) == len(ref)
+        if ok:
+            for a, b in zip(ev, ref):
+                if not np.isfinite(b.t):
+                    ok &= (not np.isfinite(float(a["t"]))) and np.sign(float(a["t"])) == np.sign(b.t)
+                    continue
+                ok &= abs(float(a["t"]) - b.t) <= 1e-5 * max(abs(b.t), 10.0)
+                ok &= int(a["is_exit"]) == b.is_exit and int(a["material_offset"]) == b.material_offset
+                ok &= max(abs(float(x) - y) for x, y in zip(a["normal"], b.normal)) <= 2e-4
+                ok &= max(abs(float(x) - y) for x, y in zip(a["uv"], b.uv)) <= 2e-4
+        bad += 0 if ok else 1
+    return bad
+
+
+def test_every_csg_operator_and_volume_over_csg(ctx):
+    from raytracer_amd.renderer import NativeScene
+    mats = [ColoredLambertian((0.1 * i, 0.5, 0.5)) for i in range(1, 9)]
+    iso = ColoredIsotropic((1, 1, 1))
+    cyl = lambda tr, k: Cylinder(tr, 0.55, 4, bottom=mats[k], top=mats[k + 1], side=mats[k + 2])
+    shapes = {
+        "union3": Union(cyl(T.translate(0, -2, 0), 0), cyl(T.rotation_deg(90, "x") * T.translate(0, -2, 0), 1),
+                        cyl(T.rotation_deg(90, "z") * T.translate(0, -2, 0), 2)),
+        "intersection2": Intersection(Cuboid(T.translate(-1, -1, -1), (2, 2, 2), mats[0]), Sphere((0, 0, 0), 1.3, mats[1])),
+        "subtract_box_union": Subtract(Cuboid(T.translate(-1, -1, -1), (2, 2, 2), mats[3]),
+                                       Union(cyl(T.translate(0, -2, 0), 0), cyl(T.rotation_deg(90, "x") * T.translate(0, -2, 0), 4),
+                                             Sphere((1, 1, 1), 0.7, mats[5]))),
+        "half_sphere": Intersection(Sphere((0, 0, 0), 1.5, mats[2]), Quad((-4, 0.2, -4), (0, 0, 8), (8, 0, 0), mats[6])),
+        "eight_leaves": Union(*[Sphere((0.6 * i - 2.1, 0, 0), 0.5, mats[i]) for i in range(8)]),
+    }
+    for name, shape in shapes.items():
+        nat = NativeScene(ctx)
+        sid = shape.as_impl(SceneEncoder(nat))
+        nat.commit()
+        orc = ob.OracleScene()
+        oid = shape.as_impl(SceneEncoder(orc))
+        rays = random_rays(1500, 21, radius=7.0, aim_radius=2.0)
+        bad = _interval_mismatches(nat, sid, orc, oid, rays)
+        print(name, "mismatches", bad)
+        assert bad <= 3, name
+    # a volume whose base is a CSG shape: several intervals, one scripted draw each
+    fog = ConstantDensityVolume(Subtract(Cuboid(T.translate(-2, -1, -1), (4, 2, 2), iso), Sphere((0, 0, 0), 0.8, iso)), 0.7)
+    nat = NativeScene(ctx)
+    sid = fog.as_impl(SceneEncoder(nat))
+    nat.commit()
+    orc = ob.OracleScene()
+    oid = fog.as_impl(SceneEncoder(orc))
+    rays = random_rays(1500, 22, radius=7.0, aim_radius=1.5)
+    bad = _interval_mismatches(nat, sid, orc, oid, rays, scripted=[0.3, 0.9, 0.05, 0.6])
+    print("fog over csg mismatches", bad)
+    assert bad <= 3
+
+
+def test_sphere_cloud_bulk_entry_point(ctx):
+    """100k spheres through rt_add_sphere_objects: stats, BVH depth bound, first hits."""
+    from raytracer_amd.renderer import NativeScene, camera_rays
+    cloud = scenes.SphereCloud(100_000, 42)
+    nat = NativeScene(ctx)
+    cloud.encode(nat)
+    nat.commit()
+    st = nat.stats()
+    assert st["n_objects"] == 100_000 and st["n_nodes"] == 99_999 and st["bvh_depth"] <= 24
+    orc = ob.OracleScene()
+    cloud.encode(orc)
+    orc.commit()
+    rays = camera_rays(ctx, cloud.camera, RenderConfig(1, 1, 1, 42, 0), 160, 90).astype(np.float32)
+    g, r = nat.first_hit(rays), orc.first_hit(rays)
+    same = g["object"] == r["object"]
+    hit = same & (r["object"] >= 0)
+    assert same.mean() > 0.999 and hit.sum() > 1000
+    assert np.abs(g["t"][hit] - r["t"][hit]).max() <= 1e-5 * 520      # reach: camera distance + cloud diagonal
+    assert (g["material_offset"][hit] == r["material_offset"][hit]).all()
+
+
+def test_full_size_properties_1080p():
+    """BASELINE sizes are too large for the oracle; properties that hold at any size:
+    linearity in samples (two halves of the sample range add up to the whole, to the
+    order of float adds), determinism of the wavefront pipeline, non-negativity."""
+    from raytracer_amd.renderer import Renderer
+    scene = scenes.random_spheres(1)
+    w, h = 1920, 1080
+    whole = Renderer(scene, w, h)
+    whole.draw(8, 50, 1)
+    a = Renderer(scene, w, h, ctx=whole.ctx)
+    a.draw(4, 50, 1, first_sample=0)
+    a.draw(4, 50, 1, first_sample=4)
+    torch.cuda.synchronize()
+    x, y = whole.accum, a.accum
+    assert torch.isfinite(x).all() and (x >= 0).all()
+    assert (x - y).abs().max().item() <= 1e-4 * max(1.0, x.abs().max().item())
+    wf1 = Renderer(scene, w, h, pipeline=abi.RT_PIPELINE_WAVEFRONT, ctx=whole.ctx)
+    wf1.draw(2, 50, 1)
+    torch.cuda.synchronize()
+    first = wf1.accum.clone()
+    wf1.reset()
+    wf1.draw(2, 50, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(first, wf1.accum)          # per-sample slots + ordered sums: bit-reproducible
+    f2 = Renderer(scene, w, h, ctx=whole.ctx)
+    f2.draw(2, 50, 1)
+    torch.cuda.synchronize()
+    assert (f2.accum - first).abs().max().item() <= 1e-4 * max(1.0, first.abs().max().item())
