@@ -41,14 +41,14 @@ def make_scene(name):
 
 def cpu_baseline(name):
     """The CPU oracle (double precision restatement of the reference renderer) timed on a
-    bounded sample of the same workload: the same scene at 480x270, 16 spp."""
+    bounded sample of the same workload: the same scene at 960x540, 32 spp."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_bridge as ob
     scene, w, h, spp, depth, seed = make_scene(name)
     if name.startswith("cfg5"):
         return None
     orc = ob.oracle_scene_from(scene)
-    cw, ch, cspp = min(w, 480), min(h, 270), 16
+    cw, ch, cspp = min(w, 960), min(h, 540), 32        # ~15-25 s of CPU work
     threads = min(16, os.cpu_count() or 1)
     orc.render(scene.camera, RenderConfig(1, depth, 1, seed, 0), cw, ch, threads=threads)      # warm
     t0 = time.perf_counter()
@@ -138,8 +138,12 @@ def main():
             samples_launch = w * h * spp * args.steps / k_n
             f_launch = (flops if k_name == "k_fused" else trace_flops) * samples_launch
             achieved = f_launch / (k_ms / k_n * 1e-3) / 1e12
+            traffic = None      # HBM bytes per launch from the PMC passes kept under profiles/
+            tfile = os.path.join(ROOT, "profiles", "r1_traffic_%s.json" % args.workload)
+            if os.path.exists(tfile) and k_name == "k_fused":
+                traffic = json.load(open(tfile))["hbm_bytes_per_sample"] * samples_launch
             out["roofline"] = {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": None, "kernel": k_name,
+                               "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": traffic, "kernel": k_name,
                                "kernel_ms_avg": k_ms / k_n, "launches": k_n,
                                "flops_per_sample": flops, "algorithmic_bytes_per_sample": nbytes,
                                "algorithmic_GBps": nbytes * samples_launch / (k_ms / k_n * 1e-3) / 1e9}
