@@ -780,9 +780,13 @@ RT_DEV f3 perlin_color(const RtDevScene &s, uint32_t id, f3 point) {
     return madd(c1 - c0, t, c0);
 }
 
+// TEXTURES = false compiles the image / Perlin paths out (scenes without such materials).
+template <bool TEXTURES>
 RT_DEV f3 material_color(const RtDevScene &s, const Material &m, const HitRecord &h) {
-    if (m.kind == 2u || m.kind == 5u) return sample_image(s, m.texture, h.u, h.v);
-    if (m.kind == 3u || m.kind == 6u) return perlin_color(s, m.texture, h.point);
+    if (TEXTURES) {
+        if (m.kind == 2u || m.kind == 5u) return sample_image(s, m.texture, h.u, h.v);
+        if (m.kind == 3u || m.kind == 6u) return perlin_color(s, m.texture, h.point);
+    }
     return m.albedo;
 }
 
@@ -797,6 +801,7 @@ RT_DEV float schlick(float cos_theta, float eta) {
 
 // One scattering event, MaterialsImpl.h:147-215.  Returns false when the path ends here
 // (emissive surface, or metal absorbing a reflection that points below the surface).
+template <bool TEXTURES>
 RT_DEV bool scatter(const RtDevScene &s, const Material &m, f3 d, const HitRecord &h, Pcg &g,
                     f3 &emitted, f3 &attenuation, f3 &new_d) {
     emitted = mk3(0, 0, 0);
@@ -813,14 +818,14 @@ RT_DEV bool scatter(const RtDevScene &s, const Material &m, f3 d, const HitRecor
             if (len_sq > RT_MIN_LEN_SQ) { new_d = v * __builtin_amdgcn_rsqf(len_sq); break; }
             rv = random_unit_vector_3d(g);
         }
-        attenuation = material_color(s, m, h);
+        attenuation = material_color<TEXTURES>(s, m, h);
         return true;
     }
     case 4: case 5: case 6: {      // metal
         f3 refl = madd(h.normal, -2.0f * dot(d, h.normal), d);
         refl = madd(rv, m.fuzz, refl);
         if (dot(refl, h.normal) < 0.0f) return false;
-        attenuation = material_color(s, m, h);
+        attenuation = material_color<TEXTURES>(s, m, h);
         new_d = normalize3(refl);
         return true;
     }

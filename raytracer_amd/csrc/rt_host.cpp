@@ -216,6 +216,7 @@ struct Builder {
     std::vector<float> nodes;      // 16 floats per node
     uint32_t max_depth = 0;
     bool sah = false;
+    uint32_t depth_limit = RT_STACK_DEPTH;   // small scenes are kept within 16 levels: the 16-entry-stack kernel holds more waves
 
     static void put_box(float *dst, const Box3 &b) { for (int a = 0; a < 3; a++) { dst[2 * a] = b.mn[a]; dst[2 * a + 1] = b.mx[a]; } }
 
@@ -304,7 +305,7 @@ struct Builder {
             // fits the traversal stack
             uint32_t need = 1;
             while ((1ull << need) < (hi - lo)) need++;
-            if (depth + 2 + need < RT_STACK_DEPTH) mid = split_sah(lo, hi);
+            if (depth + 2 + need < depth_limit) mid = split_sah(lo, hi);
         }
         if (mid == lo || mid == hi) mid = split_median(lo, hi, all);
         uint32_t idx = (uint32_t)(nodes.size() / 16);
@@ -722,6 +723,7 @@ int rt_scene_commit(RtScene *sc) {
     // ---- BVH over the objects
     Builder bld;
     bld.sah = sc->bvh_builder == RT_BVH_SAH;
+    if (sc->objects.size() + sc->bulk_mats.size() <= 4096) bld.depth_limit = 16;
     bld.items.reserve(sc->objects.size() + n_bulk);
     uint32_t feat = 0;
     for (size_t o = 0; o < sc->objects.size(); o++) {
@@ -905,7 +907,7 @@ int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, i
     hipError_t e;
     if (pipeline == RT_PIPELINE_FUSED) {
         if (workspace_bytes < RT_FUSED_WORKSPACE) return fail(RT_ERR_INVALID, "workspace too small");
-        e = rt_render_fused(sc->dev, sc->feat, cam, r, sc->refill | (sc->node_min << 8) | (getenv("RT_PROFILE_PHASES") ? 0x10000u : 0u), accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);
+        e = rt_render_fused(sc->dev, sc->feat, sc->stats.bvh_depth, cam, r, sc->refill | (sc->node_min << 8) | (getenv("RT_PROFILE_PHASES") ? 0x10000u : 0u), accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);
     } else if (pipeline == RT_PIPELINE_WAVEFRONT) {
         if (workspace_bytes < rt_wavefront_bytes((uint32_t)width * (uint32_t)height))
             return fail(RT_ERR_INVALID, "workspace too small");

@@ -228,7 +228,7 @@ RT_DEV bool shade_path(const RtDevScene &s, uint32_t background, uint32_t max_de
         m = load_material(s, h.material);
     }
     f3 emitted, atten, nd;
-    bool did = scatter(s, m, d, h, g, emitted, atten, nd);
+    bool did = scatter<(FEAT & RT_FEAT_TEXTURE) != 0>(s, m, d, h, g, emitted, atten, nd);
     rad = rad + thr * emitted;
     if (!did) return false;
     thr = thr * atten;
@@ -357,14 +357,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_accumulate(const float4 *sample
 // PROF = true is a diagnostic build: it counts, per phase, wave-level executions, the lanes
 // that took part, and shader cycles, into 16 words behind the work counter.  Its run time
 // means nothing (the stamps serialise the phases).
-#ifndef RT_FUSED_WPS
-#define RT_FUSED_WPS 4      // waves per SIMD the register allocation of k_fused is bounded for
-#endif
-template <int FEAT, bool PROF>
-__global__ __launch_bounds__(RT_BLOCK, RT_FUSED_WPS) void k_fused(RtDevScene s, RtDevCamera cam, RtDevRender rc, float *accum,
+// STACK: LDS stack entries per lane; WPS: waves per SIMD the register allocation is bounded
+// for.  Spheres-only scenes whose BVH is at most 16 deep run at 8 waves per SIMD (64 VGPRs,
+// 19 KB of LDS per workgroup); everything else at 5 (96 VGPRs, 27 KB).
+template <int FEAT, bool PROF, int STACK, int WPS>
+__global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, RtDevCamera cam, RtDevRender rc, float *accum,
                                                      uint32_t *counter, uint32_t n_items, uint32_t tiles_x,
                                                      uint32_t n_tiles, uint32_t chunk_spp, uint32_t knobs) {
-    __shared__ uint32_t stack_mem[RT_STACK_DEPTH * RT_BLOCK];
+    __shared__ uint32_t stack_mem[STACK * RT_BLOCK];
     __shared__ float tile_acc[RT_WAVES][192];
     constexpr bool SIMPLE = !(FEAT & RT_FEAT_XPRIM);
     const uint32_t refill = knobs & 255u, node_min = (knobs >> 8) & 255u;
@@ -611,12 +611,12 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
     return hipSuccess;
 }
 
-template <int FEAT>
+template <int FEAT, int STACK, int WPS>
 static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, const RtDevRender &rc, float *accum,
-                               uint32_t *counter, uint32_t refill, hipStream_t stream, RtKernelTimer *timer) {
+                               uint32_t *counter, uint32_t knobs, hipStream_t stream, RtKernelTimer *timer) {
     uint32_t tiles_x = (rc.width + 7u) / 8u, tiles_y = (rc.height + 7u) / 8u, n_tiles = tiles_x * tiles_y;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
     int grid = device_cus() * occ;
     // enough work items that the dynamic queue evens out the waves: >= 8 per resident wave
     uint32_t want_items = (uint32_t)grid * RT_WAVES * 8u;
@@ -625,27 +625,31 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     n_chunks = (rc.spp + chunk_spp - 1u) / chunk_spp;
     uint32_t n_items = n_tiles * n_chunks;
     grid = (int)std::min<uint32_t>((uint32_t)grid, (n_items + RT_WAVES - 1u) / RT_WAVES);
-    hipError_t e = hipMemsetAsync(counter, 0, (refill & 0x10000u) ? 512 : 256, stream);
+    const bool prof = (knobs & 0x10000u) != 0;
+    hipError_t e = hipMemsetAsync(counter, 0, prof ? 512 : 256, stream);
     if (e != hipSuccess) return e;
     if (timer) timer->begin(stream);
-    if (refill & 0x10000u)
-        k_fused<FEAT, true><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, refill);
+    if (prof)
+        k_fused<FEAT, true, STACK, WPS><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
     else
-        k_fused<FEAT, false><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, refill);
+        k_fused<FEAT, false, STACK, WPS><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
     if (timer) timer->end(stream);
     return hipGetLastError();
 }
 
-hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc, uint32_t refill, float *accum,
-                           void *workspace, size_t workspace_bytes, hipStream_t stream, RtKernelTimer *timer) {
+hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_depth, const RtDevCamera &cam, RtDevRender rc,
+                           uint32_t knobs, float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
+                           RtKernelTimer *timer) {
     if (rc.width == 0 || rc.height == 0 || rc.spp == 0) return hipSuccess;
     if (workspace_bytes < RT_FUSED_WORKSPACE) return hipErrorInvalidValue;
     if (timer) timer->name = "k_fused";
     uint32_t *counter = (uint32_t *)workspace;
     switch (feat & 3u) {
-    case 0: return fused_launch<0>(s, cam, rc, accum, counter, refill, stream, timer);
-    case 1: return fused_launch<1>(s, cam, rc, accum, counter, refill, stream, timer);
-    case 2: return fused_launch<2>(s, cam, rc, accum, counter, refill, stream, timer);
-    default: return fused_launch<3>(s, cam, rc, accum, counter, refill, stream, timer);
+    case 0:
+        if (bvh_depth <= 16) return fused_launch<0, 16, 8>(s, cam, rc, accum, counter, knobs, stream, timer);
+        return fused_launch<0, RT_STACK_DEPTH, 5>(s, cam, rc, accum, counter, knobs, stream, timer);
+    case 1: return fused_launch<1, RT_STACK_DEPTH, 5>(s, cam, rc, accum, counter, knobs, stream, timer);
+    case 2: return fused_launch<2, RT_STACK_DEPTH, 5>(s, cam, rc, accum, counter, knobs, stream, timer);
+    default: return fused_launch<3, RT_STACK_DEPTH, 5>(s, cam, rc, accum, counter, knobs, stream, timer);
     }
 }

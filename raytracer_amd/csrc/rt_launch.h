@@ -81,8 +81,8 @@ hipError_t rt_launch_resolve(const float *accum, float inv_samples, int width, i
 hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc,
                                float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
                                RtKernelTimer *timer);
-hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc,
-                           uint32_t refill, float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
+hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_depth, const RtDevCamera &cam, RtDevRender rc,
+                           uint32_t knobs, float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
                            RtKernelTimer *timer);
 
 #define RT_WAVEFRONT_BATCH_SPP 8u      // samples per pixel resident in the path queues at once
