@@ -239,29 +239,51 @@ RT_DEV bool shade_path(const RtDevScene &s, uint32_t background, uint32_t max_de
 }
 
 // ------------------------------------------------------------------ wavefront pipeline
+// The path queues are split into RT_WF_SHARDS shards, each with its own live counter on
+// its own 128-byte line: one returning atomic per workgroup per 256 paths on one of eight
+// words, instead of one per wave on a single word (a single word takes ~88 returning
+// atomics per microsecond, which would cap the first bounces at ~6 Gpaths/s).
+// Workgroup b works on shard b % 8 (the blocks that share b % 8 share an XCD under
+// round-robin placement, so a shard's counter and queue stay in one L2; that is a speed
+// matter only).  Paths are dealt to the shards in rounds of 256 so that every shard holds
+// an even sample of the image.
+#define RT_WF_SHARDS 8u
+#define RT_WF_COUNTER_STRIDE 32u     // uint32 words between counters (128 B)
+
 struct WfQueues {
     float4 *ray_o[2], *ray_d[2], *thr[2], *rad[2];
     uint4 *rng[2];
     float4 *hit, *sample_rad;
-    uint32_t *counts;
+    uint32_t *counts;        // [queue][shard], RT_WF_COUNTER_STRIDE apart
+    uint32_t shard_cap;      // slots per shard
 };
+RT_DEV uint32_t *wf_counter(const WfQueues &q, int queue, uint32_t shard) {
+    return q.counts + ((uint32_t)queue * RT_WF_SHARDS + shard) * RT_WF_COUNTER_STRIDE;
+}
 
 // Ray generation: path i of the batch is sample i / npix of pixel i % npix.
 __global__ __launch_bounds__(RT_BLOCK) void k_wf_raygen(WfQueues q, RtDevCamera cam, RtDevRender rc, uint32_t batch_spp) {
     uint32_t npix = rc.width * rc.height, total = npix * batch_spp;
     uint64_t seed = ((uint64_t)rc.seed_hi << 32) | rc.seed_lo;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { q.counts[0] = total; q.counts[1] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x < RT_WF_SHARDS) {
+        uint32_t sh = threadIdx.x, full = total >> 8, rem = total & 255u;
+        uint32_t cnt = (full / RT_WF_SHARDS) * 256u + (sh < full % RT_WF_SHARDS ? 256u : 0u) + (sh == full % RT_WF_SHARDS ? rem : 0u);
+        *wf_counter(q, 0, sh) = cnt;
+        *wf_counter(q, 1, sh) = 0;
+    }
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < total; i += gridDim.x * RT_BLOCK) {
         uint32_t pix = i % npix, sidx = i / npix;
         uint32_t x = pix % rc.width, y = pix / rc.width;
         Pcg g = sample_stream(seed, rc.first_sample + sidx, x, y);
         f3 o, d;
         camera_ray(cam, x, y, g, o, d);
-        q.ray_o[0][i] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
-        q.ray_d[0][i] = make_float4(d.x, d.y, d.z, __uint_as_float(0u));
-        q.thr[0][i] = make_float4(1.f, 1.f, 1.f, 0.f);
-        q.rad[0][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        q.rng[0][i] = make_uint4((uint32_t)g.state, (uint32_t)(g.state >> 32), (uint32_t)g.inc, (uint32_t)(g.inc >> 32));
+        uint32_t chunk = i >> 8;
+        uint32_t slot = (chunk % RT_WF_SHARDS) * q.shard_cap + (chunk / RT_WF_SHARDS) * 256u + (i & 255u);
+        q.ray_o[0][slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
+        q.ray_d[0][slot] = make_float4(d.x, d.y, d.z, __uint_as_float(0u));
+        q.thr[0][slot] = make_float4(1.f, 1.f, 1.f, 0.f);
+        q.rad[0][slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        q.rng[0][slot] = make_uint4((uint32_t)g.state, (uint32_t)(g.state >> 32), (uint32_t)g.inc, (uint32_t)(g.inc >> 32));
     }
 }
 
@@ -269,9 +291,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_raygen(WfQueues q, RtDevCamera 
 template <int FEAT>
 __global__ __launch_bounds__(RT_BLOCK) void k_wf_extend(RtDevScene s, WfQueues q, int cur) {
     __shared__ uint32_t stack[RT_STACK_DEPTH * RT_BLOCK];
-    uint32_t count = q.counts[cur];
-    if (blockIdx.x == 0 && threadIdx.x == 0) q.counts[cur ^ 1] = 0;   // shade appends to the other queue
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < count; i += gridDim.x * RT_BLOCK) {
+    const uint32_t shard = blockIdx.x % RT_WF_SHARDS, lb = blockIdx.x / RT_WF_SHARDS, nb = gridDim.x / RT_WF_SHARDS;
+    const uint32_t count = *wf_counter(q, cur, shard);
+    if (lb == 0 && threadIdx.x == 0) *wf_counter(q, cur ^ 1, shard) = 0;   // shade appends to the other queue
+    for (uint32_t j = lb * RT_BLOCK + threadIdx.x; j < count; j += nb * RT_BLOCK) {
+        uint32_t i = shard * q.shard_cap + j;
         float4 ro = q.ray_o[cur][i], rd = q.ray_d[cur][i];
         uint64_t key = 0;
         if (FEAT & RT_FEAT_XPRIM) {
@@ -286,23 +310,25 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_extend(RtDevScene s, WfQueues q
 }
 
 // Shade: scatter every live path of queue `cur`; survivors are appended, densely, to the
-// other queue (wave ballot + one atomic per wave); finished samples go to their slot.
+// same shard of the other queue (wave ballots, one atomic per workgroup per 256 paths);
+// finished samples go to their slot.
 template <int FEAT>
 __global__ __launch_bounds__(RT_BLOCK) void k_wf_shade(RtDevScene s, WfQueues q, int cur, uint32_t background,
                                                         uint32_t max_depth) {
-    const uint32_t lane = lane_id();
-    const uint32_t wave = (blockIdx.x * RT_BLOCK + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * RT_BLOCK) >> 6;
-    const uint32_t count = q.counts[cur];
+    __shared__ uint32_t wave_count[RT_WAVES];
+    __shared__ uint32_t block_base;
+    const uint32_t lane = lane_id(), wid = threadIdx.x >> 6;
+    const uint32_t shard = blockIdx.x % RT_WF_SHARDS, lb = blockIdx.x / RT_WF_SHARDS, nb = gridDim.x / RT_WF_SHARDS;
+    const uint32_t count = *wf_counter(q, cur, shard);
     const int nxt = cur ^ 1;
-    for (uint32_t base = wave * 64u; base < count; base += n_waves * 64u) {
-        uint32_t i = base + lane;
+    for (uint32_t jb = lb * RT_BLOCK; jb < count; jb += nb * RT_BLOCK) {     // uniform over the workgroup
+        uint32_t j = jb + threadIdx.x, i = shard * q.shard_cap + j;
         bool survive = false;
         f3 o, d, thr, rad;
         uint32_t pid = 0, depth = 0;
         Pcg g;
         g.state = g.inc = 0;
-        if (i < count) {
+        if (j < count) {
             float4 ro = q.ray_o[cur][i], rd = q.ray_d[cur][i], t4 = q.thr[cur][i], r4 = q.rad[cur][i], h4 = q.hit[i];
             uint4 rr = q.rng[cur][i];
             o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z);
@@ -316,19 +342,25 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_shade(RtDevScene s, WfQueues q,
             if (!survive) q.sample_rad[pid] = make_float4(rad.x, rad.y, rad.z, 0.f);
         }
         uint64_t mask = __ballot(survive);
-        if (mask) {
-            uint32_t slot0 = 0;
-            if (lane == 0) slot0 = atomicAdd(&q.counts[nxt], (uint32_t)__popcll(mask));
-            slot0 = __shfl(slot0, 0);
-            if (survive) {
-                uint32_t j = slot0 + prefix_rank(mask);
-                q.ray_o[nxt][j] = make_float4(o.x, o.y, o.z, __uint_as_float(pid));
-                q.ray_d[nxt][j] = make_float4(d.x, d.y, d.z, __uint_as_float(depth));
-                q.thr[nxt][j] = make_float4(thr.x, thr.y, thr.z, 0.f);
-                q.rad[nxt][j] = make_float4(rad.x, rad.y, rad.z, 0.f);
-                q.rng[nxt][j] = make_uint4((uint32_t)g.state, (uint32_t)(g.state >> 32), (uint32_t)g.inc, (uint32_t)(g.inc >> 32));
-            }
+        if (lane == 0) wave_count[wid] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (uint32_t w = 0; w < RT_WAVES; w++) tot += wave_count[w];
+            block_base = tot ? atomicAdd(wf_counter(q, nxt, shard), tot) : 0u;
         }
+        __syncthreads();
+        if (survive) {
+            uint32_t before = 0;
+            for (uint32_t w = 0; w < wid; w++) before += wave_count[w];
+            uint32_t k = shard * q.shard_cap + block_base + before + prefix_rank(mask);
+            q.ray_o[nxt][k] = make_float4(o.x, o.y, o.z, __uint_as_float(pid));
+            q.ray_d[nxt][k] = make_float4(d.x, d.y, d.z, __uint_as_float(depth));
+            q.thr[nxt][k] = make_float4(thr.x, thr.y, thr.z, 0.f);
+            q.rad[nxt][k] = make_float4(rad.x, rad.y, rad.z, 0.f);
+            q.rng[nxt][k] = make_uint4((uint32_t)g.state, (uint32_t)(g.state >> 32), (uint32_t)g.inc, (uint32_t)(g.inc >> 32));
+        }
+        __syncthreads();          // wave_count / block_base are rewritten by the next round
     }
 }
 
@@ -493,15 +525,22 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, RtDevCame
 }
 
 // ------------------------------------------------------------------ launchers
+#define RT_WF_HEADER 4096u          // the shard counters
+static uint32_t wf_shard_cap(uint32_t capacity) {
+    uint32_t per = (capacity + RT_WF_SHARDS - 1u) / RT_WF_SHARDS;
+    return (per + 255u) / 256u * 256u + 256u;      // whole rounds of 256, plus the ragged last round
+}
 size_t rt_wavefront_bytes(uint32_t capacity) {
-    return 256 + (size_t)capacity * (2 * 5 * 16 + 16 + 16);
+    size_t slots = (size_t)wf_shard_cap(capacity) * RT_WF_SHARDS;
+    return RT_WF_HEADER + slots * (2 * 5 * 16 + 16) + (size_t)capacity * 16;
 }
 
 void rt_wavefront_carve(void *workspace, uint32_t capacity, RtWavefrontBuffers &b) {
     char *p = (char *)workspace;
     b.counts = (uint32_t *)p;
-    p += 256;
-    size_t stride = (size_t)capacity * 16;
+    p += RT_WF_HEADER;
+    b.shard_cap = wf_shard_cap(capacity);
+    size_t stride = (size_t)b.shard_cap * RT_WF_SHARDS * 16;
     for (int k = 0; k < 2; k++) {
         b.ray_o[k] = (float4 *)p; p += stride;
         b.ray_d[k] = (float4 *)p; p += stride;
@@ -568,11 +607,13 @@ static hipError_t wavefront_batch(const RtDevScene &s, const RtDevCamera &cam, c
         k_wf_shade<FEAT><<<grid, RT_BLOCK, 0, stream>>>(s, q, cur, cam.background, rc.max_depth);
         // the queues drain geometrically: look at the live count now and then, and stop early
         if (bounce >= 7 && (bounce & 3u) == 3u && bounce + 1 < rc.max_depth) {
-            uint32_t live = 0;
-            hipError_t e = hipMemcpyAsync(&live, q.counts + (cur ^ 1), sizeof(live), hipMemcpyDeviceToHost, stream);
+            uint32_t header[RT_WF_HEADER / 4];
+            hipError_t e = hipMemcpyAsync(header, q.counts, RT_WF_HEADER, hipMemcpyDeviceToHost, stream);
             if (e != hipSuccess) return e;
             e = hipStreamSynchronize(stream);
             if (e != hipSuccess) return e;
+            uint32_t live = 0;
+            for (uint32_t sh = 0; sh < RT_WF_SHARDS; sh++) live += header[((uint32_t)(cur ^ 1) * RT_WF_SHARDS + sh) * RT_WF_COUNTER_STRIDE];
             if (live == 0) break;
         }
     }
@@ -585,12 +626,13 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
     uint32_t npix = rc.width * rc.height;
     if (npix == 0 || rc.spp == 0) return hipSuccess;
     if (workspace_bytes < rt_wavefront_bytes(npix)) return hipErrorInvalidValue;
-    uint32_t max_batch = (uint32_t)std::min<size_t>(RT_WAVEFRONT_BATCH_SPP, (workspace_bytes - 256) / ((size_t)npix * 192));
+    uint32_t max_batch = RT_WAVEFRONT_BATCH_SPP;
+    while (max_batch > 1 && rt_wavefront_bytes(npix * max_batch) > workspace_bytes) max_batch--;
     RtWavefrontBuffers b;
     rt_wavefront_carve(workspace, npix * max_batch, b);
     WfQueues q;
     for (int k = 0; k < 2; k++) { q.ray_o[k] = b.ray_o[k]; q.ray_d[k] = b.ray_d[k]; q.thr[k] = b.thr[k]; q.rad[k] = b.rad[k]; q.rng[k] = b.rng[k]; }
-    q.hit = b.hit; q.sample_rad = b.sample_rad; q.counts = b.counts;
+    q.hit = b.hit; q.sample_rad = b.sample_rad; q.counts = b.counts; q.shard_cap = b.shard_cap;
     if (timer) timer->name = "k_wf_extend";
     uint32_t total_spp = rc.spp, first = rc.first_sample;
     for (uint32_t s0 = 0; s0 < total_spp; s0 += max_batch) {
@@ -599,6 +641,7 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
         r.first_sample = first + s0;
         r.spp = batch;
         int grid = std::min(blocks_for((size_t)npix * batch), device_cus() * 8);
+        grid = (grid + (int)RT_WF_SHARDS - 1) / (int)RT_WF_SHARDS * (int)RT_WF_SHARDS;
         hipError_t e;
         switch (feat & 3u) {
         case 0: e = wavefront_batch<0>(s, cam, r, batch, q, accum, stream, timer, grid); break;

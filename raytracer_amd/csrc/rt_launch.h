@@ -61,8 +61,8 @@ struct RtWavefrontBuffers {
     uint4 *rng[2];
     float4 *hit;
     float4 *sample_rad;
-    uint32_t *counts;         // [0], [1]: live paths of queue 0 / 1
-    uint32_t capacity;
+    uint32_t *counts;         // live paths per [queue][shard]
+    uint32_t capacity, shard_cap;
 };
 
 size_t rt_wavefront_bytes(uint32_t capacity);
