@@ -385,7 +385,13 @@ struct CsgIter {
     bool is_exit, leaf_exit;
 };
 
-RT_DEV bool csg_lookup(const CsgIter &it, uint32_t mask) { return (it.truth[mask >> 5] >> (mask & 31u)) & 1u; }
+RT_DEV bool csg_lookup(const CsgIter &it, uint32_t mask) {
+    // select chain instead of a runtime index: keeps the table in registers
+    uint32_t hi = mask >> 5, w = it.truth[0];
+#pragma unroll
+    for (uint32_t k = 1; k < 8; k++) w = hi == k ? it.truth[k] : w;
+    return (w >> (mask & 31u)) & 1u;
+}
 
 RT_DEV void csg_begin(const RtDevScene &s, uint32_t idx, f3 o, f3 d, CsgIter &it) {
     const RtDevCsg &c = s.csg[idx];
@@ -493,7 +499,6 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
     // Constant-density volume, RenderableImpl.h:737-777: one free-flight draw per interval of
     // the base shape; a scatter inside the interval is followed by the interval's exit.
     const RtDevCdv cv = s.cdv[idx];
-    Pcg vr = pcg_seed(volume_key, (uint64_t)(s.cdv_obj[idx] + 1u));
     uint32_t draw = 0;
     uint32_t bkind = (cv.base >> RT_KIND_SHIFT) & 7u;
     if (bkind != RT_KIND_CSG) {
@@ -501,13 +506,17 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
         if (!span_valid(sp)) return;
         float t1 = fmaxf(0.0f, sp.t0), t2 = sp.t1;
         if (!(t1 < t2)) return;
-        float u = scripted ? scripted[draw % n_scripted] : rnd(vr);
+        if (found && best.t <= t1) return;      // nothing inside the medium can beat the current hit
+        float u;
+        if (scripted) u = scripted[draw % n_scripted];
+        else { Pcg vr = pcg_seed(volume_key, (uint64_t)(s.cdv_obj[idx] + 1u)); u = rnd(vr); }
         float t = fmaf(logf(1.0f - u), cv.neg_inv_density, t1);
         if (!(t <= t2)) return;
         if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = ref; best.code = RT_CODE_SCATTER | sp.tag0; found = true; }
         else if (in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = ref; best.code = sp.tag1; found = true; }
         return;
     }
+    Pcg vr = pcg_seed(volume_key, (uint64_t)(s.cdv_obj[idx] + 1u));
     CsgIter it;
     csg_begin(s, cv.base & RT_INDEX_MASK, o, d, it);
     uint32_t interval = 0;

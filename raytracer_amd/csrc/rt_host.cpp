@@ -77,7 +77,8 @@ struct RtScene {
     std::vector<float> bulk_spheres;       // cx, cy, cz, r
     std::vector<uint32_t> bulk_mats;
     int bvh_builder = RT_BVH_SAH;
-    uint32_t refill = 48, node_min = 32;
+    uint32_t refill = 48;
+    int node_min = -1;      // -1: chosen at render time from what the scene holds
     bool committed = false;
     std::vector<void *> device_allocs;
     RtDevScene dev{};
@@ -843,7 +844,7 @@ int rt_scene_set_option(RtScene *sc, int option, int value) {
         return RT_OK;
     case RT_OPTION_NODE_MIN:
         if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "node minimum must be 0..64");
-        sc->node_min = (uint32_t)value;
+        sc->node_min = value;
         return RT_OK;
     default:
         return fail(RT_ERR_INVALID, "unknown option");
@@ -907,7 +908,11 @@ int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, i
     hipError_t e;
     if (pipeline == RT_PIPELINE_FUSED) {
         if (workspace_bytes < RT_FUSED_WORKSPACE) return fail(RT_ERR_INVALID, "workspace too small");
-        e = rt_render_fused(sc->dev, sc->feat, sc->stats.bvh_depth, cam, r, sc->refill | (sc->node_min << 8) | (getenv("RT_PROFILE_PHASES") ? 0x10000u : 0u), accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);
+        // leaf tests of cylinders, boxes, CSG shapes and volumes cost several node steps: such
+        // scenes let node steps run on nearly empty waves so that the leaf tests find full ones
+        const uint32_t node_min = sc->node_min >= 0 ? (uint32_t)sc->node_min : ((sc->feat & 1u) ? 8u : 32u);
+        const uint32_t knobs = sc->refill | (node_min << 8) | (getenv("RT_PROFILE_PHASES") ? 0x10000u : 0u);
+        e = rt_render_fused(sc->dev, sc->feat, sc->stats.bvh_depth, cam, r, knobs, accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);
     } else if (pipeline == RT_PIPELINE_WAVEFRONT) {
         if (workspace_bytes < rt_wavefront_bytes((uint32_t)width * (uint32_t)height))
             return fail(RT_ERR_INVALID, "workspace too small");

@@ -391,7 +391,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_accumulate(const float4 *sample
 // means nothing (the stamps serialise the phases).
 // STACK: LDS stack entries per lane; WPS: waves per SIMD the register allocation is bounded
 // for.  Spheres-only scenes whose BVH is at most 16 deep run at 8 waves per SIMD (64 VGPRs,
-// 19 KB of LDS per workgroup); everything else at 5 (96 VGPRs, 27 KB).
+// 19 KB of LDS per workgroup), other sphere scenes at 5 (96 VGPRs, 27 KB), scenes with
+// cylinders, boxes, quads, CSG shapes or volumes at 4 (128 VGPRs: at 96 their leaf tests
+// spill and run at half the rate).
 template <int FEAT, bool PROF, int STACK, int WPS>
 __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, RtDevCamera cam, RtDevRender rc, float *accum,
                                                      uint32_t *counter, uint32_t n_items, uint32_t tiles_x,
@@ -691,8 +693,8 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
     case 0:
         if (bvh_depth <= 16) return fused_launch<0, 16, 8>(s, cam, rc, accum, counter, knobs, stream, timer);
         return fused_launch<0, RT_STACK_DEPTH, 5>(s, cam, rc, accum, counter, knobs, stream, timer);
-    case 1: return fused_launch<1, RT_STACK_DEPTH, 5>(s, cam, rc, accum, counter, knobs, stream, timer);
+    case 1: return fused_launch<1, RT_STACK_DEPTH, 4>(s, cam, rc, accum, counter, knobs, stream, timer);
     case 2: return fused_launch<2, RT_STACK_DEPTH, 5>(s, cam, rc, accum, counter, knobs, stream, timer);
-    default: return fused_launch<3, RT_STACK_DEPTH, 5>(s, cam, rc, accum, counter, knobs, stream, timer);
+    default: return fused_launch<3, RT_STACK_DEPTH, 4>(s, cam, rc, accum, counter, knobs, stream, timer);
     }
 }

@@ -1,4 +1,4 @@
-set -e
-timeout -k 10 600 python -u -m pytest tests -x -q --timeout 300 --timeout-method thread -m gpu 2>&1 | tail -2
-timeout -k 10 200 python bench.py --pipeline wavefront --spp 64 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys;d=json.loads(sys.stdin.read());print('wavefront', round(d['value']), round(d['ms_per_step'],2), d['roofline']['kernel_ms_avg'])"
+for w in cfg2_random_spheres_1080p cfg3_cornell_smoke_1080p cfg4_csg_textured_1080p; do
+  timeout -k 10 200 python bench.py --workload $w --spp 32 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys;d=json.loads(sys.stdin.read());print('$w', round(d['value']), round(d['ms_per_step'],2), d['roofline'])" || exit 1
+done
