@@ -144,10 +144,14 @@ def main():
             samples_launch = w * h * spp * args.steps / k_n
             f_launch = (flops if k_name == "k_fused" else trace_flops) * samples_launch
             achieved = f_launch / (k_ms / k_n * 1e-3) / 1e12
-            traffic = None      # HBM bytes per launch from the PMC passes kept under profiles/
-            tfile = os.path.join(ROOT, "profiles", "r1_traffic_%s.json" % args.workload)
+            # HBM bytes per launch from the PMC passes kept under profiles/ (they cannot be collected in
+            # this process); only quoted when they were measured at this launch size
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "r1c_traffic_%s.json" % args.workload)
             if os.path.exists(tfile) and k_name == "k_fused":
-                traffic = json.load(open(tfile))["hbm_bytes_per_sample"] * samples_launch
+                measured = json.load(open(tfile))
+                if measured["samples_per_launch"] == samples_launch:
+                    traffic = measured["hbm_bytes_per_launch"]
             out["roofline"] = {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": traffic, "kernel": k_name,
                                "kernel_ms_avg": k_ms / k_n, "launches": k_n,
