@@ -28,15 +28,7 @@ from raytracer_amd.scene import RenderConfig  # noqa: E402
 FP32_VALU_PEAK_TFLOPS = 157.3      # MI355X vector FP32 peak (= its FP32 matrix peak)
 
 
-def make_scene(name):
-    make, w, h, spp, depth, seed = scenes.WORKLOADS[name]
-    if name.startswith("cfg5"):
-        scene = make(1_000_000, seed)
-    elif name.startswith(("cfg3",)):
-        scene = make()
-    else:
-        scene = make(seed)
-    return scene, w, h, spp, depth, seed
+make_scene = scenes.make_workload
 
 
 def cpu_baseline(name):
@@ -70,6 +62,7 @@ def main():
     ap.add_argument("--bvh", default="sah", choices=["sah", "median"])
     ap.add_argument("--refill", type=int, default=0)
     ap.add_argument("--node-min", type=int, default=-1)
+    ap.add_argument("--nodes", default="auto", choices=["auto", "f32", "f16"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,7 +87,8 @@ def main():
         spp = args.spp
     pipeline = abi.RT_PIPELINE_FUSED if args.pipeline == "fused" else abi.RT_PIPELINE_WAVEFRONT
     r = Renderer(scene, w, h, pipeline=pipeline, device_ordinal=local_rank,
-                 bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_MEDIAN_SPLIT, refill=args.refill or None, node_min=None if args.node_min < 0 else args.node_min)
+                 bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_MEDIAN_SPLIT, refill=args.refill or None, node_min=None if args.node_min < 0 else args.node_min,
+                 nodes={"auto": abi.RT_NODES_AUTO, "f32": abi.RT_NODES_F32, "f16": abi.RT_NODES_F16}[args.nodes])
 
     def step(i):
         # rank g renders sample indices [ (i*world + g)*spp, +spp ): disjoint over ranks and steps

@@ -227,9 +227,14 @@ int rt_scene_stats(const RtScene *, RtSceneStats *out);
  * (RayTracingKit/Hittable.swift:609-631), RT_BVH_SAH (default) a binned surface-area
  * heuristic; hit results do not depend on the choice.  RT_OPTION_REFILL_THRESHOLD: how many
  * lanes of a wave must be waiting before the fused kernel leaves its traversal loop.
- * RT_OPTION_NODE_MIN: below how many lanes on inner nodes the kernel turns to waiting leaf tests. */
-enum RtOption { RT_OPTION_BVH_BUILDER = 1, RT_OPTION_REFILL_THRESHOLD = 2, RT_OPTION_NODE_MIN = 3 };
+ * RT_OPTION_NODE_MIN: below how many lanes on inner nodes the kernel turns to waiting leaf tests.
+ * RT_OPTION_NODE_FORMAT (before commit): how rt_render's fused kernel reads BVH nodes.
+ * RT_NODES_F16 stores the child boxes as halves rounded outward (32-byte nodes, half the
+ * fetch work; boxes only cull, so hits are the same), RT_NODES_F32 keeps the 64-byte nodes,
+ * RT_NODES_AUTO (default) takes halves unless a box plane lies beyond +-60000. */
+enum RtOption { RT_OPTION_BVH_BUILDER = 1, RT_OPTION_REFILL_THRESHOLD = 2, RT_OPTION_NODE_MIN = 3, RT_OPTION_NODE_FORMAT = 4 };
 enum RtBvhBuilder { RT_BVH_MEDIAN_SPLIT = 0, RT_BVH_SAH = 1 };
+enum RtNodeFormat { RT_NODES_AUTO = 0, RT_NODES_F32 = 1, RT_NODES_F16 = 2 };
 int rt_scene_set_option(RtScene *, int option, int value);
 
 /* ---- queries (parity surface) ------------------------------------------------ */

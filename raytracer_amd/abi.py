@@ -7,7 +7,8 @@ import ctypes as C
 
 RT_CSG_UNION, RT_CSG_INTERSECTION, RT_CSG_SUBTRACT = 0, 1, 2
 RT_PIPELINE_WAVEFRONT, RT_PIPELINE_FUSED = 0, 1
-RT_OPTION_BVH_BUILDER, RT_OPTION_REFILL_THRESHOLD, RT_OPTION_NODE_MIN = 1, 2, 3
+RT_OPTION_BVH_BUILDER, RT_OPTION_REFILL_THRESHOLD, RT_OPTION_NODE_MIN, RT_OPTION_NODE_FORMAT = 1, 2, 3, 4
+RT_NODES_AUTO, RT_NODES_F32, RT_NODES_F16 = 0, 1, 2
 RT_BVH_MEDIAN_SPLIT, RT_BVH_SAH = 0, 1
 RT_CSG_MAX_LEAVES = 8
 RT_MAX_EVENTS = 16

@@ -625,6 +625,45 @@ RT_DEV void trav_node(const float4 *nodes, Trav &t, float tmin, uint32_t *stack)
     }
 }
 
+// The same step on the 32-byte node form: words 0..5 hold, per axis, the two children's min
+// planes (left in the low half, right in the high half) and then their max planes; words
+// 6, 7 the refs.  Which word holds the near planes depends only on the sign of the ray
+// direction, so one select per word replaces the min/max pair per plane pair, and the
+// half -> float widening rides inside the FMA (v_fma_mix_f32).
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+RT_DEV v2f slab_pair(uint32_t packed, float inv, float oid) {
+    v2h h = __builtin_bit_cast(v2h, packed);
+    v2f r = {fmaf((float)h.x, inv, oid), fmaf((float)h.y, inv, oid)};
+    return r;
+}
+RT_DEV void trav_node16(const uint4 *nodes16, Trav &t, float tmin, uint32_t *stack) {
+    const uint4 *n = nodes16 + 2u * t.cur;
+    uint4 a = n[0], b = n[1];
+    const bool px = t.inv_d.x >= 0.0f, py = t.inv_d.y >= 0.0f, pz = t.inv_d.z >= 0.0f;
+    // (left, right) entry and exit distances per axis; a NaN (inf - inf) is dropped by max3/min3
+    v2f nx = slab_pair(px ? a.x : a.y, t.inv_d.x, t.oid.x), fx = slab_pair(px ? a.y : a.x, t.inv_d.x, t.oid.x);
+    v2f ny = slab_pair(py ? a.z : a.w, t.inv_d.y, t.oid.y), fy = slab_pair(py ? a.w : a.z, t.inv_d.y, t.oid.y);
+    v2f nz = slab_pair(pz ? b.x : b.y, t.inv_d.z, t.oid.z), fz = slab_pair(pz ? b.y : b.x, t.inv_d.z, t.oid.z);
+    float limit = t.best.t;
+    float tl = fmaxf(fmaxf(nx.x, ny.x), fmaxf(nz.x, tmin)), tr = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, tmin));
+    float el = fminf(fminf(fx.x, fy.x), fminf(fz.x, limit)), er = fminf(fminf(fx.y, fy.y), fminf(fz.y, limit));
+    bool hl = tl <= el, hr = tr <= er;
+    uint32_t lref = b.z, rref = b.w;
+    hr = hr && rref != RT_REF_NONE;
+    if (hl && hr) {
+        bool left_first = tl <= tr;
+        stack[t.sp * RT_BLOCK] = left_first ? rref : lref;
+        t.sp++;
+        t.cur = left_first ? lref : rref;
+    } else if (hl) {
+        t.cur = lref;
+    } else if (hr) {
+        t.cur = rref;
+    } else {
+        trav_pop(t, stack);
+    }
+}
+
 // Runs one ray to completion (parity kernels and the wavefront extend stage).
 template <bool SIMPLE>
 RT_DEV bool trace(const RtDevScene &s, f3 o, f3 d, float tmin, float tmax, uint64_t volume_key,

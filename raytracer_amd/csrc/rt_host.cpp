@@ -79,6 +79,8 @@ struct RtScene {
     int bvh_builder = RT_BVH_SAH;
     uint32_t refill = 48;
     int node_min = -1;      // -1: chosen at render time from what the scene holds
+    int node_format = RT_NODES_AUTO;
+    bool use_nodes16 = false;
     bool committed = false;
     std::vector<void *> device_allocs;
     RtDevScene dev{};
@@ -211,6 +213,36 @@ bool eval_csg(const RtScene &sc, int id, uint32_t mask, int &next_leaf) {
 }
 
 struct BuildItem { uint32_t ref; Box3 box; float c[3]; };
+
+// IEEE half nearest to x on the side asked for (up: >= x, down: <= x), so that a box
+// written in halves encloses the float box.  Out-of-range planes land on +-65504 or +-inf.
+uint16_t half_toward(float x, bool up) {
+    _Float16 h = (_Float16)x;                 // round to nearest
+    float back = (float)h;
+    uint16_t bits;
+    memcpy(&bits, &h, 2);
+    if (up ? back < x : back > x) {
+        const bool neg = (bits & 0x8000u) != 0;
+        if (up) bits = neg ? (bits == 0x8000u ? (uint16_t)0x0001u : (uint16_t)(bits - 1)) : (uint16_t)(bits + 1);
+        else bits = neg ? (uint16_t)(bits + 1) : (bits == 0x0000u ? (uint16_t)0x8001u : (uint16_t)(bits - 1));
+    }
+    return bits;
+}
+
+// The 32-byte node form from the 64-byte one.
+std::vector<uint32_t> pack_nodes16(const std::vector<float> &nodes) {
+    std::vector<uint32_t> out(nodes.size() / 2);
+    for (size_t i = 0; i < nodes.size() / 16; i++) {
+        const float *n = nodes.data() + 16 * i;
+        uint32_t *o = out.data() + 8 * i;
+        for (int a = 0; a < 3; a++) {        // per axis: (left min, right min), (left max, right max)
+            o[2 * a] = (uint32_t)half_toward(n[2 * a], false) | ((uint32_t)half_toward(n[6 + 2 * a], false) << 16);
+            o[2 * a + 1] = (uint32_t)half_toward(n[2 * a + 1], true) | ((uint32_t)half_toward(n[6 + 2 * a + 1], true) << 16);
+        }
+        memcpy(o + 6, n + 12, 8);
+    }
+    return out;
+}
 
 struct Builder {
     std::vector<BuildItem> items;
@@ -787,6 +819,19 @@ int rt_scene_commit(RtScene *sc) {
     if (!any_rot) sphere_rot.clear();
     int rc = RT_OK;
     if ((rc = upload(sc, bld.nodes, &d.nodes)) < 0) return rc;
+    {
+        // halves hold box planes up to 65504; beyond that (or on request) the render kernel
+        // reads the float nodes
+        float reach = 0.f;
+        for (size_t i = 0; i < bld.nodes.size(); i += 16)
+            for (int k = 0; k < 12; k++)
+                if (std::isfinite(bld.nodes[i + k])) reach = std::max(reach, std::fabs(bld.nodes[i + k]));
+        sc->use_nodes16 = sc->node_format == RT_NODES_F16 || (sc->node_format == RT_NODES_AUTO && reach <= 60000.f);
+        if (sc->use_nodes16) {
+            std::vector<uint32_t> n16 = pack_nodes16(bld.nodes);
+            if ((rc = upload(sc, n16, &d.nodes16)) < 0) return rc;
+        }
+    }
     if ((rc = upload(sc, spheres, &d.spheres)) < 0) return rc;
     if ((rc = upload(sc, sphere_rot, &d.sphere_rot)) < 0) return rc;
     if ((rc = upload(sc, sphere_mat, &d.sphere_mat)) < 0) return rc;
@@ -841,6 +886,11 @@ int rt_scene_set_option(RtScene *sc, int option, int value) {
     case RT_OPTION_REFILL_THRESHOLD:
         if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "refill threshold must be 1..64");
         sc->refill = (uint32_t)value;
+        return RT_OK;
+    case RT_OPTION_NODE_FORMAT:
+        if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
+        if (value != RT_NODES_AUTO && value != RT_NODES_F32 && value != RT_NODES_F16) return fail(RT_ERR_INVALID, "unknown node format");
+        sc->node_format = value;
         return RT_OK;
     case RT_OPTION_NODE_MIN:
         if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "node minimum must be 0..64");
@@ -911,7 +961,8 @@ int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, i
         // leaf tests of cylinders, boxes, CSG shapes and volumes cost several node steps: such
         // scenes let node steps run on nearly empty waves so that the leaf tests find full ones
         const uint32_t node_min = sc->node_min >= 0 ? (uint32_t)sc->node_min : ((sc->feat & 1u) ? 8u : 32u);
-        const uint32_t knobs = sc->refill | (node_min << 8) | (getenv("RT_PROFILE_PHASES") ? 0x10000u : 0u);
+        const uint32_t knobs = sc->refill | (node_min << 8) | (getenv("RT_PROFILE_PHASES") ? 0x10000u : 0u) |
+                               (sc->use_nodes16 ? 0x20000u : 0u);
         e = rt_render_fused(sc->dev, sc->feat, sc->stats.bvh_depth, cam, r, knobs, accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);
     } else if (pipeline == RT_PIPELINE_WAVEFRONT) {
         if (workspace_bytes < rt_wavefront_bytes((uint32_t)width * (uint32_t)height))

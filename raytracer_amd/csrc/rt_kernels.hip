@@ -394,7 +394,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_accumulate(const float4 *sample
 // 19 KB of LDS per workgroup), other sphere scenes at 5 (96 VGPRs, 27 KB), scenes with
 // cylinders, boxes, quads, CSG shapes or volumes at 4 (128 VGPRs: at 96 their leaf tests
 // spill and run at half the rate).
-template <int FEAT, bool PROF, int STACK, int WPS>
+template <int FEAT, bool PROF, int STACK, int WPS, bool NODE16>
 __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, RtDevCamera cam, RtDevRender rc, float *accum,
                                                      uint32_t *counter, uint32_t n_items, uint32_t tiles_x,
                                                      uint32_t n_tiles, uint32_t chunk_spp, uint32_t knobs) {
@@ -407,6 +407,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, RtDevCame
     float *acc = tile_acc[threadIdx.x >> 6];
     const uint64_t seed = ((uint64_t)rc.seed_hi << 32) | rc.seed_lo;
     const float4 *nodes = (const float4 *)s.nodes;
+    const uint4 *nodes16 = (const uint4 *)s.nodes16;
     unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // {execs, lanes, cycles} x {shade, raygen, node, leaf}
     unsigned long long stamp = 0;
 #define RT_PROF_BEGIN() do { if (PROF) stamp = __builtin_amdgcn_s_memtime(); } while (0)
@@ -493,7 +494,10 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, RtDevCame
                     if (n_inner == 0) break;
                     if (n_inner < node_min && __ballot(!inner && t.cur != RT_REF_NONE)) break;
                     RT_PROF_BEGIN();
-                    if (inner) trav_node(nodes, t, RT_T_MIN, stack);
+                    if (inner) {
+                        if (NODE16) trav_node16(nodes16, t, RT_T_MIN, stack);
+                        else trav_node(nodes, t, RT_T_MIN, stack);
+                    }
                     RT_PROF_END(2, inner);
                 }
                 RT_PROF_BEGIN();
@@ -656,12 +660,12 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
     return hipSuccess;
 }
 
-template <int FEAT, int STACK, int WPS>
+template <int FEAT, int STACK, int WPS, bool NODE16>
 static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, const RtDevRender &rc, float *accum,
                                uint32_t *counter, uint32_t knobs, hipStream_t stream, RtKernelTimer *timer) {
     uint32_t tiles_x = (rc.width + 7u) / 8u, tiles_y = (rc.height + 7u) / 8u, n_tiles = tiles_x * tiles_y;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS, NODE16>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
     int grid = device_cus() * occ;
     // enough work items that the dynamic queue evens out the waves: >= 8 per resident wave
     uint32_t want_items = (uint32_t)grid * RT_WAVES * 8u;
@@ -675,9 +679,9 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     if (e != hipSuccess) return e;
     if (timer) timer->begin(stream);
     if (prof)
-        k_fused<FEAT, true, STACK, WPS><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
+        k_fused<FEAT, true, STACK, WPS, NODE16><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
     else
-        k_fused<FEAT, false, STACK, WPS><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
+        k_fused<FEAT, false, STACK, WPS, NODE16><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
     if (timer) timer->end(stream);
     return hipGetLastError();
 }
@@ -689,12 +693,16 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
     if (workspace_bytes < RT_FUSED_WORKSPACE) return hipErrorInvalidValue;
     if (timer) timer->name = "k_fused";
     uint32_t *counter = (uint32_t *)workspace;
+    const bool n16 = (knobs & 0x20000u) != 0 && s.nodes16 != nullptr;
+#define RT_FUSED(F, ST, W) (n16 ? fused_launch<F, ST, W, true>(s, cam, rc, accum, counter, knobs, stream, timer) \
+                                : fused_launch<F, ST, W, false>(s, cam, rc, accum, counter, knobs, stream, timer))
     switch (feat & 3u) {
     case 0:
-        if (bvh_depth <= 16) return fused_launch<0, 16, 8>(s, cam, rc, accum, counter, knobs, stream, timer);
-        return fused_launch<0, RT_STACK_DEPTH, 5>(s, cam, rc, accum, counter, knobs, stream, timer);
-    case 1: return fused_launch<1, RT_STACK_DEPTH, 4>(s, cam, rc, accum, counter, knobs, stream, timer);
-    case 2: return fused_launch<2, RT_STACK_DEPTH, 5>(s, cam, rc, accum, counter, knobs, stream, timer);
-    default: return fused_launch<3, RT_STACK_DEPTH, 4>(s, cam, rc, accum, counter, knobs, stream, timer);
+        if (bvh_depth <= 16) return RT_FUSED(0, 16, 8);
+        return RT_FUSED(0, RT_STACK_DEPTH, 5);
+    case 1: return RT_FUSED(1, RT_STACK_DEPTH, 4);
+    case 2: return RT_FUSED(2, RT_STACK_DEPTH, 5);
+    default: return RT_FUSED(3, RT_STACK_DEPTH, 4);
     }
+#undef RT_FUSED
 }

@@ -3,6 +3,11 @@
 // Device layout (all buffers live in HBM, written once at rt_scene_commit):
 //   nodes      4 x float4 per BVH node: both child boxes and both child references, so one
 //              64-byte fetch serves two box tests.
+//   nodes16    the same nodes in 32 bytes: box planes as IEEE halves rounded outward (a
+//              superset of every box, so culling with them loses no hit), refs as they are.
+//              A wave-wide node fetch occupies the CU's address unit for as many cycles as
+//              each lane requests bytes, which makes the 64-byte form the render kernel's
+//              tightest resource; this form halves it.
 //   spheres    float4 (cx, cy, cz, r) per sphere: the whole geometry of the common case
 //              in one 16-byte load; material ids and UV rotations are separate streams
 //              that only the shade stage touches.
@@ -65,6 +70,8 @@ struct RtDevPerlin {
 // Everything a kernel needs to trace and shade; passed by value.
 struct RtDevScene {
     const float *nodes;            // n_nodes x 16 floats
+    const uint32_t *nodes16;       // n_nodes x 8 words: the same boxes as 12 halves rounded outward (per axis the two
+                                   // children's min planes, then their max planes), then the two refs
     const float *spheres;          // n x 4
     const float *sphere_rot;       // n x 12 (three padded columns) or nullptr when every rotation is identity
     const uint32_t *sphere_mat;

@@ -154,13 +154,14 @@ class Renderer:
     the float accumulator; the accumulator resets when the size changes (:172-180)."""
 
     def __init__(self, scene, width, height, pipeline=abi.RT_PIPELINE_FUSED, device_ordinal=0, ctx=None, dedup=True,
-                 bvh=abi.RT_BVH_SAH, refill=None, node_min=None):
+                 bvh=abi.RT_BVH_SAH, refill=None, node_min=None, nodes=abi.RT_NODES_AUTO):
         self.ctx = ctx or Context(device_ordinal)
         self.scene = scene
         self.camera = scene.camera
         self.native = NativeScene(self.ctx)
         scene.encode(self.native, dedup=dedup)
         self.native.set_option(abi.RT_OPTION_BVH_BUILDER, bvh)
+        self.native.set_option(abi.RT_OPTION_NODE_FORMAT, nodes)
         if refill:
             self.native.set_option(abi.RT_OPTION_REFILL_THRESHOLD, refill)
         if node_min is not None:

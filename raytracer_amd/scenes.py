@@ -304,6 +304,19 @@ WORKLOADS = {
     "cfg5_sphere_cloud_4k": (SphereCloud, 3840, 2160, 8192, 50, 42),
 }
 
+
+def make_workload(name):
+    """(scene, width, height, spp, depth, seed) of a named measurement workload."""
+    make, w, h, spp, depth, seed = WORKLOADS[name]
+    if make is SphereCloud:
+        scene = make(1_000_000, seed)
+    elif make is cornell_smoke:
+        scene = make()
+    else:
+        scene = make(seed)
+    return scene, w, h, spp, depth, seed
+
+
 DEMO_SCENES = {
     "simpleBalls": simple_balls,
     "singleCylinder": single_cylinder,

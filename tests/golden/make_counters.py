@@ -23,8 +23,7 @@ from raytracer_amd.scene import RenderConfig  # noqa: E402
 names = sys.argv[1:] or ["cfg1_random_spheres_400x225", "cfg2_random_spheres_1080p", "cfg3_cornell_smoke_1080p",
                          "cfg4_csg_textured_1080p"]
 for name in names:
-    make, w, h, spp, depth, seed = scenes.WORKLOADS[name]
-    scene = make(seed) if name.startswith(("cfg1", "cfg2", "cfg4")) else make()
+    scene, w, h, spp, depth, seed = scenes.make_workload(name)
     if w > 480:
         w, h = w // 4, h // 4
     orc = ob.oracle_scene_from(scene)

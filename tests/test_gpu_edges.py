@@ -105,6 +105,27 @@ def test_bvh_builders_give_identical_hits(ctx):
     assert b.stats()["bvh_depth"] <= 8 and a.stats()["n_nodes"] == b.stats()["n_nodes"]
 
 
+@pytest.mark.parametrize("make", [lambda: scenes.random_spheres(1), lambda: scenes.csg_textured(7), scenes.cornell_smoke,
+                                  lambda: scenes.SphereCloud(20000, 5)])
+def test_half_precision_nodes_render_the_same_image(ctx, make):
+    """The 32-byte nodes hold boxes rounded outward: they cull less, never more, so the
+    image is the one the float nodes give up to the order of the float sums."""
+    from raytracer_amd.renderer import Renderer
+    scene = make()
+    imgs = []
+    for fmt in (abi.RT_NODES_F32, abi.RT_NODES_F16):
+        r = Renderer(scene, 256, 144, ctx=ctx, nodes=fmt)
+        r.draw(8, 20, 3)
+        torch.cuda.synchronize()
+        imgs.append(r.accum.clone())
+    a, b = imgs
+    assert torch.isfinite(b).all()
+    scale = max(1.0, a.abs().max().item())
+    close = ((a - b).abs() <= 1e-4 * scale).float().mean().item()
+    print("pixels equal to 1e-4:", close)
+    assert close > 0.999          # a path that meets an exact tie between two objects may take the other one
+
+
 def _interval_mismatches(nat, sid, orc, oid, rays, scripted=None, key=0):
     got = nat.intervals(sid, rays, scripted=scripted, volume_key=key)
     bad = 0

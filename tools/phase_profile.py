@@ -8,8 +8,7 @@ from raytracer_amd import scenes, abi
 from raytracer_amd.renderer import Renderer
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg2_random_spheres_1080p"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-make, w, h, _, depth, seed = scenes.WORKLOADS[name]
-scene = make() if name.startswith("cfg3") else make(seed)
+scene, w, h, _, depth, seed = scenes.make_workload(name)
 r = Renderer(scene, w, h)
 r.draw(spp, depth, seed)
 torch.cuda.synchronize()
