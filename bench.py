@@ -141,7 +141,7 @@ def main():
             # HBM bytes per launch from the PMC passes kept under profiles/ (they cannot be collected in
             # this process); only quoted when they were measured at this launch size
             traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r1c_traffic_%s.json" % args.workload)
+            tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
             if os.path.exists(tfile) and k_name == "k_fused":
                 measured = json.load(open(tfile))
                 if measured["samples_per_launch"] == samples_launch:
