@@ -279,6 +279,16 @@ int rt_render(RtScene *, const RtCameraConfig *, const RtRenderConfig *, int pip
 int rt_resolve_rgb8(RtContext *, const float *accum_dev, uint32_t n_samples, int width, int height,
                     uint8_t *rgbx_out_dev, void *stream);
 
+/* The app's accumulate-and-present step, Shaders.metal:151-158 / ContentView.swift:182-235:
+ * pass_sum_dev holds ONE pass (rt_render into a zeroed W*H*3 buffer with samples_per_pixel
+ * samples); its mean, clamped to 1, is blended with weight 1/pass_counter into the 10-bit
+ * running mean `acc_rgb10a2_dev` (the app's rgb10a2Uint accumulator texture, one word per
+ * pixel: r bits 0-9, g 10-19, b 20-29) and sqrt(mean) is written to `bgra8_out_dev` as the
+ * drawable's bgra8Unorm pixel.  pass_counter = 1 starts a new image (the old accumulator
+ * content has weight 0). */
+int rt_progressive_present(RtContext *, const float *pass_sum_dev, uint32_t samples_per_pixel, uint32_t pass_counter,
+                           uint32_t *acc_rgb10a2_dev, uint8_t *bgra8_out_dev, int width, int height, void *stream);
+
 /* Timing of the render loop's dominant kernel on its own stream (HIP events around
  * every launch since the last reset): total milliseconds and launch count. */
 int rt_kernel_time(RtScene *, int reset, double *total_ms, uint64_t *launches, const char **kernel_name);

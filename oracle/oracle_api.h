@@ -175,6 +175,13 @@ void orc_wyrand(uint64_t seed, int n, uint64_t *out);
 /* Seeding of the per-(pixel, sample) stream; returns state and inc. */
 void orc_sample_stream(uint64_t rng_seed, uint32_t sample, uint32_t x, uint32_t y, uint64_t out_state_inc[2]);
 
+/* Progressive display step of the app's kernel (Shaders.metal:151-158): the pass mean is
+ * clamped to 1, blended into the 10-bit running mean held in `acc` (rgb10a2Uint words: r in
+ * bits 0-9, g 10-19, b 20-29) with weight 1/pass_counter, and sqrt(mean) is written as the
+ * drawable's bgra8Unorm pixel (round to nearest even).  pass_sum: n_pixels*3 radiance sums. */
+void orc_progressive_present(const float *pass_sum, uint32_t samples_per_pixel, uint32_t pass_counter,
+                             uint32_t *acc, uint8_t *bgra, int n_pixels);
+
 const char *orc_last_error(void);
 
 #ifdef __cplusplus

@@ -255,3 +255,33 @@ void orc_sample_stream(uint64_t rng_seed, uint32_t sample, uint32_t x, uint32_t 
     out_state_inc[1] = g.inc;
 }
 
+
+// Shaders.metal:151-158, one float operation at a time (this file is built with
+// -ffp-contract=off, so nothing fuses).
+void orc_progressive_present(const float *pass_sum, uint32_t samples_per_pixel, uint32_t pass_counter,
+                             uint32_t *acc, uint8_t *bgra, int n_pixels) {
+    const float half_below = std::nextafter(0.5f, 0.0f);
+    const float t = 1.0f / (float)pass_counter;
+    const float keep = 1.0f - t;
+    for (int i = 0; i < n_pixels; i++) {
+        uint32_t word = acc[i], out_word = 0;
+        uint8_t px[3];
+        for (int c = 0; c < 3; c++) {
+            float color = pass_sum[3 * (size_t)i + c] / (float)samples_per_pixel;        // :151
+            color = std::fmin(color, 1.0f);                                              // :152
+            float old_color = ((float)((word >> (10 * c)) & 1023u) + half_below) / 1024.0f;   // :153
+            float total = old_color * keep + color * t;                                  // :155
+            float scaled = total * 1024.0f;
+            uint32_t q = scaled > 0.0f ? (uint32_t)scaled : 0u;                          // :156 (ushort conversion truncates)
+            out_word |= (q > 1023u ? 1023u : q) << (10 * c);
+            float shown = std::sqrt(total);                                              // :158
+            shown = shown < 0.0f || shown != shown ? 0.0f : (shown > 1.0f ? 1.0f : shown);
+            px[c] = (uint8_t)std::nearbyint(shown * 255.0f);
+        }
+        acc[i] = out_word;
+        bgra[4 * (size_t)i + 0] = px[2];
+        bgra[4 * (size_t)i + 1] = px[1];
+        bgra[4 * (size_t)i + 2] = px[0];
+        bgra[4 * (size_t)i + 3] = 255;
+    }
+}

@@ -16,7 +16,7 @@ EXPORTS = [
     "rt_shape_sphere", "rt_shape_cylinder", "rt_shape_cuboid", "rt_shape_quad", "rt_shape_csg", "rt_shape_cdv",
     "rt_add_object", "rt_add_sphere_objects", "rt_scene_commit", "rt_scene_stats", "rt_scene_set_option",
     "rt_first_hit", "rt_intervals", "rt_camera_rays",
-    "rt_render_workspace_size", "rt_render", "rt_resolve_rgb8", "rt_kernel_time",
+    "rt_render_workspace_size", "rt_render", "rt_resolve_rgb8", "rt_progressive_present", "rt_kernel_time",
 ]
 
 
@@ -59,6 +59,7 @@ def _load():
         "rt_render": (i32, [vp, C.POINTER(abi.RtCameraConfig), C.POINTER(abi.RtRenderConfig), i32, i32, i32, vp, vp,
                             C.c_size_t, vp]),
         "rt_resolve_rgb8": (i32, [vp, vp, u32, i32, i32, vp, vp]),
+        "rt_progressive_present": (i32, [vp, vp, u32, u32, vp, vp, i32, i32, vp]),
         "rt_kernel_time": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(C.c_char_p)]),
     }
     for name in EXPORTS:

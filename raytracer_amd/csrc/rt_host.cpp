@@ -982,6 +982,16 @@ int rt_resolve_rgb8(RtContext *ctx, const float *accum_dev, uint32_t n_samples, 
     return e == hipSuccess ? RT_OK : fail_hip(e, "resolve launch");
 }
 
+int rt_progressive_present(RtContext *ctx, const float *pass_sum_dev, uint32_t samples_per_pixel, uint32_t pass_counter,
+                           uint32_t *acc_rgb10a2_dev, uint8_t *bgra8_out_dev, int width, int height, void *stream) {
+    if (!ctx || !pass_sum_dev || !acc_rgb10a2_dev || !bgra8_out_dev || width <= 0 || height <= 0)
+        return fail(RT_ERR_INVALID, "bad argument");
+    if (samples_per_pixel == 0 || pass_counter == 0) return fail(RT_ERR_INVALID, "samples_per_pixel and pass_counter start at 1");
+    hipError_t e = rt_launch_progressive_present(pass_sum_dev, samples_per_pixel, pass_counter, width, height, acc_rgb10a2_dev,
+                                                 bgra8_out_dev, as_stream(stream));
+    return e == hipSuccess ? RT_OK : fail_hip(e, "present launch");
+}
+
 int rt_kernel_time(RtScene *sc, int reset, double *total_ms, uint64_t *launches, const char **kernel_name) {
     if (!sc) return fail(RT_ERR_INVALID, "null scene");
     sc->timer.collect();

@@ -190,6 +190,34 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float *accum, float 
     ((uint32_t *)rgbx)[i] = px;
 }
 
+// Shaders.metal:151-158.  Every float operation is a correctly rounded single one
+// (contraction off; `/` and sqrtf are the IEEE ones under hipcc's defaults, unlike the
+// __fsqrt_rn / rcp shortcuts), so the 10-bit words are the ones a plain IEEE evaluation of
+// the reference's expressions gives.
+__global__ __launch_bounds__(RT_BLOCK) void k_progressive_present(const float *pass_sum, float spp, float t, int npix,
+                                                                  uint32_t *acc, uint32_t *bgra) {
+#pragma clang fp contract(off)
+    int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= npix) return;
+    const float half_below = 0.49999997f;           // nextafter(0.5f, 0)
+    const float keep = 1.0f - t;
+    uint32_t word = acc[i], out_word = 0, px = 0xFF000000u;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float color = fminf(pass_sum[3 * (size_t)i + c] / spp, 1.0f);
+        float old_color = ((float)((word >> (10 * c)) & 1023u) + half_below) / 1024.0f;
+        float total = old_color * keep + color * t;
+        float scaled = total * 1024.0f;
+        uint32_t q = scaled > 0.0f ? (uint32_t)scaled : 0u;
+        out_word |= (q > 1023u ? 1023u : q) << (10 * c);
+        float shown = sqrtf(total);
+        shown = (shown < 0.0f || shown != shown) ? 0.0f : fminf(shown, 1.0f);
+        px |= (uint32_t)rintf(shown * 255.0f) << (8 * (2 - c));      // b, g, r, a in memory
+    }
+    acc[i] = out_word;
+    bgra[i] = px;
+}
+
 // ------------------------------------------------------------------ one bounce of shading
 // Shaders.metal:102-119 for one path: adds emission / background, scatters, and says
 // whether the path goes on.  Depth exhaustion keeps what was gathered so far
@@ -591,6 +619,15 @@ hipError_t rt_launch_resolve(const float *accum, float inv_samples, int width, i
     int npix = width * height;
     if (npix <= 0) return hipSuccess;
     k_resolve<<<blocks_for(npix), RT_BLOCK, 0, stream>>>(accum, inv_samples, npix, rgbx);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_progressive_present(const float *pass_sum, uint32_t spp, uint32_t pass_counter, int width, int height,
+                                         uint32_t *acc, uint8_t *bgra, hipStream_t stream) {
+    int npix = width * height;
+    if (npix <= 0) return hipSuccess;
+    k_progressive_present<<<blocks_for(npix), RT_BLOCK, 0, stream>>>(pass_sum, (float)spp, 1.0f / (float)pass_counter, npix, acc,
+                                                                     (uint32_t *)bgra);
     return hipGetLastError();
 }
 

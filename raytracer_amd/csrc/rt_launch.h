@@ -77,6 +77,9 @@ hipError_t rt_launch_camera_rays(const RtDevCamera &cam, const RtDevRender &rc, 
                                  float *rays_out, hipStream_t stream);
 hipError_t rt_launch_resolve(const float *accum, float inv_samples, int width, int height, uint8_t *rgbx, hipStream_t stream);
 
+hipError_t rt_launch_progressive_present(const float *pass_sum, uint32_t spp, uint32_t pass_counter, int width, int height,
+                                         uint32_t *acc, uint8_t *bgra, hipStream_t stream);
+
 // spp samples per pixel starting at rc.first_sample, added to accum.
 hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc,
                                float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,

@@ -211,3 +211,68 @@ class Renderer:
         ms, n, name = C.c_double(), C.c_uint64(), C.c_char_p()
         check(lib.rt_kernel_time(self.native.h, 1 if reset else 0, C.byref(ms), C.byref(n), C.byref(name)))
         return ms.value, n.value, (name.value or b"").decode()
+
+
+class ProgressiveView:
+    """The interactive loop of the reference app (ContentView.swift:103-235) without the
+    window: every frame adds one pass of 1 sample per pixel at depth 10 with a fresh seed,
+    blends it into a 10-bit running mean and produces the bgra8 drawable; the pass counter
+    restarts when the camera or the size changes and the view pauses at 200 passes."""
+
+    MAX_PASSES = 200          # ContentView.swift:188
+    SAMPLES_PER_PASS = 1      # ContentView.swift:202
+    MAX_DEPTH = 10
+
+    def __init__(self, scene, width, height, seed=0, **renderer_args):
+        from .scene import WyRand
+        self.renderer = Renderer(scene, width, height, **renderer_args)
+        self.seeds = WyRand(seed)             # stands in for SystemRandomNumberGenerator (:201)
+        self.paused = False
+        self._alloc()
+
+    def _alloc(self):
+        r = self.renderer
+        dev = r.ctx.device
+        self.acc = torch.zeros((r.height, r.width), dtype=torch.int32, device=dev)        # rgb10a2Uint words
+        self.drawable = torch.zeros((r.height, r.width, 4), dtype=torch.uint8, device=dev)  # bgra8Unorm
+        self.pass_counter = 0
+        self.paused = False
+
+    # ---- Renderer.scene didSet / mtkView(_:drawableSizeWillChange:)  (:107-113, :172-180)
+    def set_camera(self, camera):
+        if camera != self.renderer.camera:
+            self.renderer.camera = camera
+            self.set_needs_redraw()
+
+    def resize(self, width, height):
+        self.renderer.resize(width, height)
+        self._alloc()
+
+    def set_needs_redraw(self):
+        self.pass_counter = 0
+        self.paused = False
+
+    # ---- Renderer.draw(in:)  (:182-224)
+    def draw(self, rng_seed=None):
+        """One frame.  Returns False (and does nothing) while paused."""
+        if self.paused:
+            return False
+        self.pass_counter += 1
+        if self.pass_counter >= self.MAX_PASSES:
+            self.paused = True
+        r = self.renderer
+        seed = self.seeds.next() if rng_seed is None else rng_seed
+        r.accum.zero_()
+        rc = RenderConfig(self.SAMPLES_PER_PASS, self.MAX_DEPTH, self.pass_counter, seed, 0).impl
+        cc = r.camera.impl
+        check(lib.rt_render(r.native.h, C.byref(cc), C.byref(rc), r.pipeline, r.width, r.height, r.accum.data_ptr(),
+                            r.workspace.data_ptr(), r.workspace.numel(), _stream()))
+        check(lib.rt_progressive_present(r.ctx.h, r.accum.data_ptr(), self.SAMPLES_PER_PASS, self.pass_counter,
+                                         self.acc.data_ptr(), self.drawable.data_ptr(), r.width, r.height, _stream()))
+        return True
+
+    def running_mean(self):
+        """The 10-bit accumulator decoded as the kernel reads it back (Shaders.metal:153)."""
+        w = self.acc.cpu().numpy().astype(np.uint32)
+        rgb = np.stack([(w >> (10 * c)) & 1023 for c in range(3)], axis=-1).astype(np.float32)
+        return (rgb + np.nextafter(np.float32(0.5), np.float32(0))) / np.float32(1024)

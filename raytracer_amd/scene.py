@@ -534,7 +534,7 @@ class ConstantDensityVolume(Renderable):
 
 # ---------------------------------------------------------------------------- config
 class CameraConfig:
-    """Config.swift:9-36 (plain fields; the orbit accessors of :43-59 are UI-only)."""
+    """Config.swift:9-70: plain fields plus the orbit accessor the app's sliders drive."""
 
     def __init__(self, vertical_fov=90.0, look_from=(0, 0, 0), look_at=(0, 0, -1), up=(0, 1, 0),
                  defocus_angle=0.0, focus_distance=None, background=abi.background_lighting_sky):
@@ -546,6 +546,38 @@ class CameraConfig:
         self.focus_distance = float(focus_distance) if focus_distance is not None else float(
             length(self.look_from - self.look_at))
         self.background = int(background)
+
+    # Config.swift:43-59: the camera position as yaw / pitch (degrees) and distance around look_at
+    @property
+    def relative_position(self):
+        v = (self.look_from - self.look_at).astype(np.float32)
+        d = np.float32(np.sqrt(np.float32(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])))
+        yaw = np.float32(np.arctan2(v[2], v[0])) * np.float32(180) / np.float32(np.pi)
+        pitch = np.float32(np.arctan2(v[1], np.sqrt(np.float32(v[0] * v[0] + v[2] * v[2])))) * np.float32(180) / np.float32(np.pi)
+        return float(yaw), float(pitch), float(d)
+
+    @relative_position.setter
+    def relative_position(self, ypd):
+        yaw, pitch, distance = (np.float32(x) for x in ypd)
+        rad = np.float32(np.pi) / np.float32(180)
+        y = np.sin(pitch * rad)
+        h = np.cos(pitch * rad)
+        x = h * np.cos(yaw * rad)
+        z = h * np.sin(yaw * rad)
+        self.look_from = (self.look_at + np.array([x, y, z], dtype=np.float32) * distance).astype(np.float32)
+
+    # Config.swift:99-106 (the background is not part of the comparison there either)
+    def __eq__(self, other):
+        return (isinstance(other, CameraConfig) and self.vertical_fov == other.vertical_fov
+                and np.array_equal(self.look_from, other.look_from) and np.array_equal(self.look_at, other.look_at)
+                and np.array_equal(self.up, other.up) and self.defocus_angle == other.defocus_angle
+                and self.focus_distance == other.focus_distance)
+
+    __hash__ = None
+
+    def copy(self):
+        return CameraConfig(self.vertical_fov, self.look_from.copy(), self.look_at.copy(), self.up.copy(),
+                            self.defocus_angle, self.focus_distance, self.background)
 
     @property
     def impl(self):

@@ -227,3 +227,16 @@ def oracle_scene_from(scene, dedup=True):
     scene.encode(sink, dedup=dedup)
     sink.commit()
     return sink
+
+
+def progressive_present(pass_sum, samples_per_pixel, pass_counter, acc):
+    """Shaders.metal:151-158 on the CPU.  pass_sum: [n, 3] float32 sums of one pass; acc:
+    [n] uint32 rgb10a2 words (updated copy returned).  Returns (acc, bgra [n, 4] uint8)."""
+    L = lib()
+    ps = np.ascontiguousarray(pass_sum, dtype=np.float32).reshape(-1, 3)
+    a = np.ascontiguousarray(acc, dtype=np.uint32).copy()
+    out = np.zeros((len(ps), 4), dtype=np.uint8)
+    L.orc_progressive_present.restype = None
+    L.orc_progressive_present(ps.ctypes.data_as(C.c_void_p), C.c_uint32(samples_per_pixel), C.c_uint32(pass_counter),
+                              a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_int(len(ps)))
+    return a, out
