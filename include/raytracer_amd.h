@@ -210,6 +210,20 @@ int rt_shape_csg(RtScene *, int op, int n_children, const int *children);
 /* ConstantDensityVolume (ConstantDensityVolume.swift:8-33; RenderableImpl.h:717-725). */
 int rt_shape_cdv(RtScene *, int base_shape, float density);
 /* RenderableGrouper.add (SceneBuffers.swift:116-119): makes a shape a scene object. */
+/* MotionBlur (RayTracingKit/Hittable.swift:528-555): `base` (a primitive or CSG shape) seen
+ * through transform.pow(time), time in [0, 1) drawn once per sample after the camera ray
+ * (Camera.swift:89; only drawn when the scene holds a moving object).  The BVH box is
+ * Transform3D.boundingBoxForAnimation (Transform.swift:93-154). */
+typedef struct RtMotion {
+    float rotation[4];      /* unit quaternion w, x, y, z with w >= 0 (Transform.swift:169-206) */
+    float translation[3];
+} RtMotion;
+int rt_shape_motion(RtScene *, int base_shape, const RtMotion *);
+/* Hittable.boundingBox (Hittable.swift:98) of any shape before padding: min xyz, max xyz. */
+int rt_shape_bounds(const RtScene *, int shape, float out_min_max[6]);
+/* Time of the rays given to rt_first_hit / rt_intervals (rt_render draws its own). */
+int rt_scene_set_time(RtScene *, float time);
+
 int rt_add_object(RtScene *, int shape);
 /* Bulk form of rt_shape_sphere + rt_add_object for n plain spheres (identity rotation):
  * center_radius holds n x 4 floats (cx, cy, cz, r).  No counterpart in the reference,

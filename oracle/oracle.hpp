@@ -158,7 +158,7 @@ template <class R> V3<R> random_unit_vector_3d(Rng &rng) {
 }
 
 // ---------------------------------------------------------------- scene storage
-enum ShapeKind { SPHERE = 0, CYLINDER = 1, CUBOID = 2, QUAD = 3, COMPOSITION = 4, CDV = 5 };
+enum ShapeKind { SPHERE = 0, CYLINDER = 1, CUBOID = 2, QUAD = 3, COMPOSITION = 4, CDV = 5, MOTION = 6 };
 
 struct Box {
     double mn[3] = {INFINITY, INFINITY, INFINITY};
@@ -184,6 +184,8 @@ struct Shape {
     // constant-density volume (RenderableImpl.h:717-725)
     int base = -1;
     double density = 0;
+    // motion blur (RayTracingKit/Hittable.swift:528-555): `base` moved by transform.pow(time)
+    double m_quat[4] = {1, 0, 0, 0}, m_trans[3] = {0, 0, 0};     // w, x, y, z
     Box box;
 };
 
@@ -206,6 +208,7 @@ struct Counters {
 };
 
 struct Scene {
+    bool animated = false;      // some shape is a MOTION: camera samples draw a time
     std::vector<Shape> shapes;
     std::vector<int> objects;
     std::vector<OrcMaterial> materials;
@@ -443,6 +446,7 @@ template <class R> struct TraceCtx {
     Counters *counters;
     Rng *scripted;           // test RNG for volume draws, or nullptr
     uint64_t cdv_state;      // PCG32 state word that keys volume draws when not scripted
+    double time = 0;         // the sample's time in [0, 1), Camera.swift:89
 };
 
 template <class R> std::unique_ptr<Enum<R>> make_enum(const TraceCtx<R> &ctx, int shape, Ray<R> ray, int object);
@@ -553,6 +557,102 @@ template <class R> struct CdvEnum final : Enum<R> {
     }
 };
 
+// ---------------------------------------------------------------- motion blur
+// Unit quaternions as RayTracingKit/Transform.swift:169-259 (w, x, y, z; w >= 0).
+struct Quat { double w, x, y, z; };
+inline Quat quat_mul(Quat a, Quat b) {                                       // :234-241
+    return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+inline void quat_rotate(Quat q, const double v[3], double out[3]) {          // :228-232
+    Quat r = quat_mul(quat_mul(q, Quat{0, v[0], v[1], v[2]}), Quat{q.w, -q.x, -q.y, -q.z});
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+inline Quat quat_pow(Quat q, double t) {                                     // :243-250
+    if (q.w == 1.0) return q;
+    double th = std::acos(q.w);
+    double sin_th = std::sqrt(1 - q.w * q.w);
+    double w2 = std::cos(th * t);
+    double scale = std::sin(th * t) / sin_th;
+    if (!std::isfinite(scale)) return {w2, 0, 0, 0};
+    return {w2, q.x * scale, q.y * scale, q.z * scale};
+}
+
+// Transform3D.boundingBoxForAnimation of a point, Transform.swift:93-140.
+inline Box animation_box_of_point(Quat q, const double tr[3], const double p[3]) {
+    double p1[3], p2[3];
+    quat_rotate(q, p, p1);
+    for (int a = 0; a < 3; a++) p2[a] = p1[a] + tr[a];
+    Box result;
+    result.add(p);
+    result.add(p2);
+    if (q.w != 1.0) {
+        const double kTau = 2 * 3.14159265358979323846264338327950288;
+        double th = 2 * std::acos(q.w);
+        double sin_th = std::sin(th), cos_th = std::cos(th);
+        auto norm_angle = [&](double x) { return x < 0 ? x + kTau : (x >= kTau ? x - kTau : x); };   // :157-166
+        auto get_p = [&](double t, double out[3]) {
+            for (int a = 0; a < 3; a++)
+                out[a] = (std::sin((1 - t) * th) / sin_th) * p[a] + (std::sin(t * th) / sin_th) * p1[a] + t * tr[a];
+        };
+        for (int a = 0; a < 3; a++) {
+            double A = th * sin_th * p[a];
+            double B = th * (cos_th * p[a] - p1[a]);
+            double C = tr[a] * sin_th;
+            double Z = C / std::sqrt(A * A + B * B);
+            if (!std::isfinite(Z) || std::fabs(Z) > 1) continue;
+            double phi = std::atan2(A, B);
+            double acos_z = std::acos(Z);
+            double t1 = norm_angle(phi + acos_z) / th, t2 = norm_angle(phi - acos_z) / th;
+            double e[3];
+            if (std::isfinite(t1) && t1 >= 0 && t1 <= 1) { get_p(t1, e); result.add(e); }
+            if (std::isfinite(t2) && t2 >= 0 && t2 <= 1) { get_p(t2, e); result.add(e); }
+        }
+    }
+    return result;
+}
+
+// Transform3D.boundingBoxForAnimation of a box, Transform.swift:142-154.
+inline Box animation_box(Quat q, const double tr[3], const Box &box) {
+    Box result;
+    if (q.w == 1.0) {
+        result.add(box);
+        double a[3], b[3];
+        for (int i = 0; i < 3; i++) { a[i] = box.mn[i] + tr[i]; b[i] = box.mx[i] + tr[i]; }
+        result.add(a);
+        result.add(b);
+    } else {
+        for (int i = 0; i < 8; i++) {
+            double p[3] = {(i & 1) ? box.mx[0] : box.mn[0], (i & 2) ? box.mx[1] : box.mn[1], (i & 4) ? box.mx[2] : box.mn[2]};
+            result.add(animation_box_of_point(q, tr, p));
+        }
+    }
+    return result;
+}
+
+// MotionBlur / Transformed, Hittable.swift:543-555,578-601: the ray goes into the frame of
+// transform.pow(time), the base is enumerated there, points and normals come back.
+template <class R> struct MotionEnum final : Enum<R> {
+    std::unique_ptr<Enum<R>> impl;
+    Xf<R> xf;
+    MotionEnum(const TraceCtx<R> &ctx, const Shape &s, Ray<R> ray, int object) {
+        Quat q = quat_pow(Quat{s.m_quat[0], s.m_quat[1], s.m_quat[2], s.m_quat[3]}, ctx.time);
+        double ex[3] = {1, 0, 0}, ey[3] = {0, 1, 0}, ez[3] = {0, 0, 1}, c0[3], c1[3], c2[3];
+        quat_rotate(q, ex, c0); quat_rotate(q, ey, c1); quat_rotate(q, ez, c2);
+        xf.c0 = v3<R>(c0); xf.c1 = v3<R>(c1); xf.c2 = v3<R>(c2);
+        xf.t = V3<R>(R(ctx.time * s.m_trans[0]), R(ctx.time * s.m_trans[1]), R(ctx.time * s.m_trans[2]));
+        impl = make_enum<R>(ctx, s.base, inverse_transform(ray, xf), object);
+    }
+    bool hasNext() const override { return impl->hasNext(); }
+    void move() override { impl->move(); }
+    bool isExit() const override { return impl->isExit(); }
+    R t() const override { return impl->t(); }
+    V3<R> point() const override { return xf.rot(impl->point()) + xf.t; }
+    V3<R> normal() const override { return xf.rot(impl->normal()); }
+    uint64_t material_offset() const override { return impl->material_offset(); }
+    void texture_coordinates(R &u, R &v) const override { impl->texture_coordinates(u, v); }
+};
+
 template <class R> std::unique_ptr<Enum<R>> make_enum(const TraceCtx<R> &ctx, int shape, Ray<R> ray, int object) {
     const Shape &s = ctx.scene->shapes[shape];
     if (ctx.counters && s.kind <= QUAD) ctx.counters->prim_tests[s.kind]++;
@@ -562,6 +662,7 @@ template <class R> std::unique_ptr<Enum<R>> make_enum(const TraceCtx<R> &ctx, in
     case CUBOID: return std::make_unique<CuboidEnum<R>>(s, ray);
     case QUAD: return std::make_unique<QuadEnum<R>>(s, ray);
     case COMPOSITION: return std::make_unique<CompositionEnum<R>>(ctx, s, ray, object);
+    case MOTION: return std::make_unique<MotionEnum<R>>(ctx, s, ray, object);
     default: return std::make_unique<CdvEnum<R>>(ctx, s, ray, object);
     }
 }
@@ -607,6 +708,7 @@ template <class R> bool hit_object(const TraceCtx<R> &ctx, int object, Ray<R> ra
     case CUBOID: { CuboidEnum<R> e(s, ray); return first_in_range(e, ray, lo, hi, hi_open, object, out); }
     case QUAD: { QuadEnum<R> e(s, ray); return first_in_range(e, ray, lo, hi, hi_open, object, out); }
     case COMPOSITION: { CompositionEnum<R> e(ctx, s, ray, object); return first_in_range(e, ray, lo, hi, hi_open, object, out); }
+    case MOTION: { MotionEnum<R> e(ctx, s, ray, object); return first_in_range(e, ray, lo, hi, hi_open, object, out); }
     default: { CdvEnum<R> e(ctx, s, ray, object); return first_in_range(e, ray, lo, hi, hi_open, object, out); }
     }
 }
@@ -703,6 +805,9 @@ inline Box shape_box(const Scene &sc, int id) {
         break;
     case CDV:
         b = shape_box(sc, s.base);
+        break;
+    case MOTION:
+        b = animation_box(Quat{s.m_quat[0], s.m_quat[1], s.m_quat[2], s.m_quat[3]}, s.m_trans, shape_box(sc, s.base));
         break;
     }
     return b;
@@ -946,10 +1051,9 @@ constexpr double kTMin = 1e-3;   // Camera.swift:117
 // Camera.swift:113-131 (recursive form), with the background of Shaders.metal:104 on a
 // miss.  At depth 0 the tail contributes nothing while emission gathered at shallower
 // bounces is kept (Camera.swift:114-122; Shaders.metal:127-128 would drop it).
-template <class R> V3<R> ray_color(const Scene &sc, uint32_t background, Ray<R> ray, int depth, Rng &rng, Counters *counters, int object_salt = 0) {
-    (void)object_salt;
+template <class R> V3<R> ray_color(const Scene &sc, uint32_t background, Ray<R> ray, int depth, Rng &rng, Counters *counters, double time = 0) {
     if (depth <= 0) return V3<R>();
-    TraceCtx<R> ctx{&sc, counters, nullptr, rng.pcg.state};
+    TraceCtx<R> ctx{&sc, counters, nullptr, rng.pcg.state, time};
     HitInfo<R> hit;
     if (!scene_hit<R>(ctx, ray, R(kTMin), kInf<R>(), hit)) return background_color<R>(background, ray.direction);
     const OrcMaterial &m = sc.materials[hit.material_offset];
@@ -957,7 +1061,7 @@ template <class R> V3<R> ray_color(const Scene &sc, uint32_t background, Ray<R> 
     ScatterResult<R> res;
     bool did = scatter<R>(sc, m, ray, hit, rng, res);
     if (!did) return res.emitted;
-    return res.emitted + res.attenuation * ray_color<R>(sc, background, res.scattered, depth - 1, rng, counters);
+    return res.emitted + res.attenuation * ray_color<R>(sc, background, res.scattered, depth - 1, rng, counters, time);
 }
 
 }  // namespace orc

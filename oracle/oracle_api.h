@@ -143,6 +143,17 @@ int orc_shape_cuboid(OrcScene *, const OrcCuboid *);
 int orc_shape_quad(OrcScene *, const OrcQuad *);
 int orc_shape_csg(OrcScene *, int op, int n, const int *children);
 int orc_shape_cdv(OrcScene *, int base, float density);
+/* MotionBlur (RayTracingKit/Hittable.swift:528-555): `base` seen through transform.pow(time),
+ * transform = unit quaternion (w, x, y, z; Transform.swift:169-259) + translation. */
+int orc_shape_motion(OrcScene *, int base, const double quat_wxyz[4], const double translation[3]);
+/* Time used by orc_enumerate / orc_first_hit (orc_render draws one per sample). */
+void orc_set_query_time(OrcScene *, double time);
+/* Bounding box of a shape as the BVH uses it (Hittable.boundingBox): min xyz, max xyz. */
+int orc_shape_bounds(OrcScene *, int shape, double out_min_max[6]);
+/* Transform3D.boundingBoxForAnimation of a point and Transform3D.pow(t).transform(p)
+ * (Transform.swift:82-140), as RayTracingKitTests/TransformTests.swift exercises them. */
+void orc_animation_box_of_point(const double quat_wxyz[4], const double translation[3], const double p[3], double out_min_max[6]);
+void orc_transform_pow(const double quat_wxyz[4], const double translation[3], double t, const double p[3], double out[3]);
 int orc_add_object(OrcScene *, int shape);               /* -> object index */
 int orc_commit(OrcScene *);                               /* builds the BVH */
 

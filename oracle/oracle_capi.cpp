@@ -7,7 +7,7 @@
 
 using namespace orc;
 
-struct OrcScene { Scene s; };
+struct OrcScene { Scene s; double query_time = 0; };
 
 static thread_local std::string g_err;
 static int fail(const std::string &m) { g_err = m; return -1; }
@@ -90,6 +90,31 @@ int orc_shape_cdv(OrcScene *s, int base, float density) {
     Shape sh; sh.kind = CDV; sh.base = base; sh.density = density;
     return push(s, std::move(sh));
 }
+int orc_shape_motion(OrcScene *s, int base, const double quat_wxyz[4], const double translation[3]) {
+    if (base < 0 || base >= (int)s->s.shapes.size()) return fail("bad base shape id");
+    if (s->s.shapes[base].kind == CDV || s->s.shapes[base].kind == MOTION) return fail("motion blur takes a primitive or a composition");
+    Shape sh; sh.kind = MOTION; sh.base = base;
+    for (int i = 0; i < 4; i++) sh.m_quat[i] = quat_wxyz[i];
+    for (int i = 0; i < 3; i++) sh.m_trans[i] = translation[i];
+    s->s.animated = true;
+    return push(s, std::move(sh));
+}
+void orc_set_query_time(OrcScene *s, double time) { s->query_time = time; }
+int orc_shape_bounds(OrcScene *s, int shape, double out_min_max[6]) {
+    if (shape < 0 || shape >= (int)s->s.shapes.size()) return fail("bad shape id");
+    Box b = shape_box(s->s, shape);
+    for (int a = 0; a < 3; a++) { out_min_max[a] = b.mn[a]; out_min_max[3 + a] = b.mx[a]; }
+    return 0;
+}
+void orc_animation_box_of_point(const double quat_wxyz[4], const double translation[3], const double p[3], double out_min_max[6]) {
+    Box b = animation_box_of_point(Quat{quat_wxyz[0], quat_wxyz[1], quat_wxyz[2], quat_wxyz[3]}, translation, p);
+    for (int a = 0; a < 3; a++) { out_min_max[a] = b.mn[a]; out_min_max[3 + a] = b.mx[a]; }
+}
+void orc_transform_pow(const double quat_wxyz[4], const double translation[3], double t, const double p[3], double out[3]) {
+    Quat q = quat_pow(Quat{quat_wxyz[0], quat_wxyz[1], quat_wxyz[2], quat_wxyz[3]}, t);
+    quat_rotate(q, p, out);
+    for (int a = 0; a < 3; a++) out[a] += t * translation[a];
+}
 int orc_add_object(OrcScene *s, int shape) {
     if (shape < 0 || shape >= (int)s->s.shapes.size()) return fail("bad shape id");
     s->s.committed = false;
@@ -99,11 +124,11 @@ int orc_add_object(OrcScene *s, int shape) {
 int orc_commit(OrcScene *s) { commit(s->s); return 0; }
 
 template <class R>
-static int enumerate_t(const Scene &sc, int shape, const double o[3], const double d[3],
+static int enumerate_t(const Scene &sc, double time, int shape, const double o[3], const double d[3],
                        const float *script, int n_script, OrcEvent *out, int max_out) {
     Rng scripted;
     scripted.script = script; scripted.n_script = n_script;
-    TraceCtx<R> ctx{&sc, nullptr, script ? &scripted : nullptr, 0};
+    TraceCtx<R> ctx{&sc, nullptr, script ? &scripted : nullptr, 0, time};
     Ray<R> ray{V3<R>(R(o[0]), R(o[1]), R(o[2])), V3<R>(R(d[0]), R(d[1]), R(d[2]))};
     auto e = make_enum<R>(ctx, shape, ray, 0);
     int n = 0;
@@ -131,16 +156,16 @@ static int enumerate_t(const Scene &sc, int shape, const double o[3], const doub
 int orc_enumerate(const OrcScene *s, int shape, int precision, const double origin[3], const double direction[3],
                   const float *scripted_rng, int n_scripted, OrcEvent *out, int max_out) {
     if (shape < 0 || shape >= (int)s->s.shapes.size()) return fail("bad shape id");
-    if (precision == ORC_F32) return enumerate_t<float>(s->s, shape, origin, direction, scripted_rng, n_scripted, out, max_out);
-    return enumerate_t<double>(s->s, shape, origin, direction, scripted_rng, n_scripted, out, max_out);
+    if (precision == ORC_F32) return enumerate_t<float>(s->s, s->query_time, shape, origin, direction, scripted_rng, n_scripted, out, max_out);
+    return enumerate_t<double>(s->s, s->query_time, shape, origin, direction, scripted_rng, n_scripted, out, max_out);
 }
 
 template <class R>
-static void first_hit_t(const Scene &sc, int n, const double *rays, double tmin, double tmax, uint64_t cdv_state, OrcHit *out) {
+static void first_hit_t(const Scene &sc, double time, int n, const double *rays, double tmin, double tmax, uint64_t cdv_state, OrcHit *out) {
     for (int i = 0; i < n; i++) {
         const double *r = rays + 6 * (size_t)i;
         Ray<R> ray{V3<R>(R(r[0]), R(r[1]), R(r[2])), V3<R>(R(r[3]), R(r[4]), R(r[5]))};
-        TraceCtx<R> ctx{&sc, nullptr, nullptr, cdv_state};
+        TraceCtx<R> ctx{&sc, nullptr, nullptr, cdv_state, time};
         HitInfo<R> h;
         OrcHit &o = out[i];
         std::memset(&o, 0, sizeof(o));
@@ -160,8 +185,8 @@ static void first_hit_t(const Scene &sc, int n, const double *rays, double tmin,
 int orc_first_hit(const OrcScene *s, int precision, int n, const double *rays, double tmin, double tmax,
                   uint64_t cdv_state, OrcHit *out) {
     if (!s->s.committed) return fail("scene not committed");
-    if (precision == ORC_F32) first_hit_t<float>(s->s, n, rays, tmin, tmax, cdv_state, out);
-    else first_hit_t<double>(s->s, n, rays, tmin, tmax, cdv_state, out);
+    if (precision == ORC_F32) first_hit_t<float>(s->s, s->query_time, n, rays, tmin, tmax, cdv_state, out);
+    else first_hit_t<double>(s->s, s->query_time, n, rays, tmin, tmax, cdv_state, out);
     return 0;
 }
 
@@ -210,7 +235,9 @@ static void render_t(const Scene &sc, const OrcCameraConfig *cc, const OrcRender
                     Rng rng;
                     rng.pcg = sample_stream(rc->rng_seed, rc->first_sample + s, (uint32_t)x, (uint32_t)y);
                     Ray<R> ray = cam.get_ray((uint32_t)x, (uint32_t)y, rng);
-                    color = color + ray_color<R>(sc, cc->background, ray, (int)rc->max_depth, rng, cnt);
+                    // Camera.swift:89: one time per sample, after the ray; only drawn when something moves
+                    double time = sc.animated ? rng.random_f<double>() : 0.0;
+                    color = color + ray_color<R>(sc, cc->background, ray, (int)rc->max_depth, rng, cnt, time);
                     if (cnt) cnt->samples++;
                 }
                 double *o = out_sum + 3 * ((size_t)row * w + col);

@@ -14,6 +14,7 @@ EXPORTS = [
     "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_abi_version",
     "rt_scene_create", "rt_scene_destroy", "rt_add_material", "rt_add_texture_rgb8",
     "rt_shape_sphere", "rt_shape_cylinder", "rt_shape_cuboid", "rt_shape_quad", "rt_shape_csg", "rt_shape_cdv",
+    "rt_shape_motion", "rt_shape_bounds", "rt_scene_set_time",
     "rt_add_object", "rt_add_sphere_objects", "rt_scene_commit", "rt_scene_stats", "rt_scene_set_option",
     "rt_first_hit", "rt_intervals", "rt_camera_rays",
     "rt_render_workspace_size", "rt_render", "rt_resolve_rgb8", "rt_progressive_present", "rt_kernel_time",
@@ -46,6 +47,9 @@ def _load():
         "rt_shape_quad": (i32, [vp, C.POINTER(abi.RtQuad)]),
         "rt_shape_csg": (i32, [vp, i32, i32, C.POINTER(i32)]),
         "rt_shape_cdv": (i32, [vp, i32, f32]),
+        "rt_shape_motion": (i32, [vp, i32, C.POINTER(abi.RtMotion)]),
+        "rt_shape_bounds": (i32, [vp, i32, C.POINTER(f32)]),
+        "rt_scene_set_time": (i32, [vp, f32]),
         "rt_add_object": (i32, [vp, i32]),
         "rt_add_sphere_objects": (i32, [vp, i32, vp, vp]),
         "rt_scene_commit": (i32, [vp]),

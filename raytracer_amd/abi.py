@@ -121,6 +121,10 @@ class RtEvent(C.Structure):
                 ("material_offset", C.c_uint32), ("is_exit", C.c_int32), ("pad", C.c_int32)]
 
 
+class RtMotion(C.Structure):
+    _fields_ = [("rotation", C.c_float * 4), ("translation", C.c_float * 3)]
+
+
 class RtSceneStats(C.Structure):
     _fields_ = [("n_objects", C.c_uint32), ("n_nodes", C.c_uint32), ("bvh_depth", C.c_uint32),
                 ("n_spheres", C.c_uint32), ("n_cylinders", C.c_uint32), ("n_cuboids", C.c_uint32),

@@ -446,6 +446,28 @@ RT_DEV bool csg_next(CsgIter &it) {
     }
 }
 
+// ------------------------------------------------------------------ motion blur
+// The frame of a moving object at `time`: transform.pow(time) = (rotation^time, time *
+// translation), RayTracingKit/Transform.swift:82-84,243-250.  Rays go into the frame
+// (Hittable.swift:578-592), normals come back out (:70-73); t is the same on both sides.
+struct MotionFrame { f3 c0, c1, c2, t; uint32_t base; };
+RT_DEV MotionFrame motion_frame(const RtDevScene &s, uint32_t idx, float time) {
+    const RtDevMotion m = s.motion[idx];
+    float a = m.half_angle * time;
+    float w = cosf(a), k = sinf(a) * m.inv_sin;
+    float x = m.qx * k, y = m.qy * k, z = m.qz * k;
+    MotionFrame f;
+    // columns of the rotation matrix of the unit quaternion (w, x, y, z)
+    f.c0 = mk3(1.0f - 2.0f * (y * y + z * z), 2.0f * (x * y + w * z), 2.0f * (x * z - w * y));
+    f.c1 = mk3(2.0f * (x * y - w * z), 1.0f - 2.0f * (x * x + z * z), 2.0f * (y * z + w * x));
+    f.c2 = mk3(2.0f * (x * z + w * y), 2.0f * (y * z - w * x), 1.0f - 2.0f * (x * x + y * y));
+    f.t = mk3(m.tx * time, m.ty * time, m.tz * time);
+    f.base = m.base;
+    return f;
+}
+RT_DEV f3 frame_in(const MotionFrame &f, f3 v) { return mk3(dot(f.c0, v), dot(f.c1, v), dot(f.c2, v)); }
+RT_DEV f3 frame_out(const MotionFrame &f, f3 v) { return madd(f.c0, v.x, madd(f.c1, v.y, f.c2 * v.z)); }
+
 // ------------------------------------------------------------------ closest hit of one object
 // What extend remembers about the closest hit; `code` lets shade rebuild the surface:
 //   primitive        tag
@@ -462,23 +484,32 @@ RT_DEV bool in_range(float t, float tmin, float tmax_incl, bool found, float bes
     return t >= tmin && (found ? t < best : t <= tmax_incl);
 }
 
-template <bool SIMPLE>
+template <bool SIMPLE, bool MOTION = false>
 RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmin, float tmax, uint64_t volume_key,
-                        const float *scripted, uint32_t n_scripted, bool &found, Best &best) {
+                        const float *scripted, uint32_t n_scripted, bool &found, Best &best, float time = 0.0f) {
     uint32_t kind = (ref >> RT_KIND_SHIFT) & 7u, idx = ref & RT_INDEX_MASK;
+    const uint32_t self = ref;           // what a hit is recorded under
+    if (MOTION && kind == RT_KIND_MOTION) {
+        MotionFrame f = motion_frame(s, idx, time);
+        o = frame_in(f, o - f.t);
+        d = frame_in(f, d);
+        ref = f.base;
+        kind = (ref >> RT_KIND_SHIFT) & 7u;
+        idx = ref & RT_INDEX_MASK;
+    }
     if (SIMPLE || kind == RT_KIND_SPHERE) {
         Span sp = sphere_span(s, idx, o, d);
         if (span_valid(sp)) {
-            if (in_range(sp.t0, tmin, tmax, found, best.t)) { best.t = sp.t0; best.ref = ref; best.code = 0; found = true; }
-            else if (in_range(sp.t1, tmin, tmax, found, best.t)) { best.t = sp.t1; best.ref = ref; best.code = 0; found = true; }
+            if (in_range(sp.t0, tmin, tmax, found, best.t)) { best.t = sp.t0; best.ref = self; best.code = 0; found = true; }
+            else if (in_range(sp.t1, tmin, tmax, found, best.t)) { best.t = sp.t1; best.ref = self; best.code = 0; found = true; }
         }
         return;
     }
     if (kind <= RT_KIND_QUAD) {
         Span sp = prim_span(s, ref, o, d);
         if (span_valid(sp)) {
-            if (in_range(sp.t0, tmin, tmax, found, best.t)) { best.t = sp.t0; best.ref = ref; best.code = sp.tag0; found = true; }
-            else if (in_range(sp.t1, tmin, tmax, found, best.t)) { best.t = sp.t1; best.ref = ref; best.code = sp.tag1; found = true; }
+            if (in_range(sp.t0, tmin, tmax, found, best.t)) { best.t = sp.t0; best.ref = self; best.code = sp.tag0; found = true; }
+            else if (in_range(sp.t1, tmin, tmax, found, best.t)) { best.t = sp.t1; best.ref = self; best.code = sp.tag1; found = true; }
         }
         return;
     }
@@ -487,7 +518,7 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
         csg_begin(s, idx, o, d, it);
         while (csg_next(it)) {
             if (in_range(it.t, tmin, tmax, found, best.t)) {
-                best.t = it.t; best.ref = ref;
+                best.t = it.t; best.ref = self;
                 best.code = it.tag | (it.leaf << 3) | ((it.leaf_exit ? 1u : 0u) << 6);
                 found = true;
                 break;
@@ -512,8 +543,8 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
         else { Pcg vr = pcg_seed(volume_key, (uint64_t)(s.cdv_obj[idx] + 1u)); u = rnd(vr); }
         float t = fmaf(logf(1.0f - u), cv.neg_inv_density, t1);
         if (!(t <= t2)) return;
-        if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = ref; best.code = RT_CODE_SCATTER | sp.tag0; found = true; }
-        else if (in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = ref; best.code = sp.tag1; found = true; }
+        if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = self; best.code = RT_CODE_SCATTER | sp.tag0; found = true; }
+        else if (in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = self; best.code = sp.tag1; found = true; }
         return;
     }
     Pcg vr = pcg_seed(volume_key, (uint64_t)(s.cdv_obj[idx] + 1u));
@@ -534,8 +565,8 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
             float t = fmaf(logf(1.0f - u), cv.neg_inv_density, t1);
             if (t <= t2) {
                 uint32_t iv = interval << RT_CODE_INTERVAL_SHIFT;
-                if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = ref; best.code = RT_CODE_SCATTER | iv | entry_code; found = true; return; }
-                if (has_exit && in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = ref; best.code = iv | exit_code; found = true; return; }
+                if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = self; best.code = RT_CODE_SCATTER | iv | entry_code; found = true; return; }
+                if (has_exit && in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = self; best.code = iv | exit_code; found = true; return; }
             }
         }
         if (!has_exit) return;
@@ -665,16 +696,16 @@ RT_DEV void trav_node16(const uint4 *nodes16, Trav &t, float tmin, uint32_t *sta
 }
 
 // Runs one ray to completion (parity kernels and the wavefront extend stage).
-template <bool SIMPLE>
+template <bool SIMPLE, bool MOTION = false>
 RT_DEV bool trace(const RtDevScene &s, f3 o, f3 d, float tmin, float tmax, uint64_t volume_key,
-                  const float *scripted, uint32_t n_scripted, uint32_t *stack, Best &best) {
+                  const float *scripted, uint32_t n_scripted, uint32_t *stack, Best &best, float time = 0.0f) {
     Trav t;
     trav_begin(t, s.root, o, d, tmax);
     const float4 *nodes = (const float4 *)s.nodes;
     while (t.cur != RT_REF_NONE) {
         while (!(t.cur & RT_REF_LEAF)) trav_node(nodes, t, tmin, stack);
         if (t.cur != RT_REF_NONE) {
-            test_object<SIMPLE>(s, t.cur & ~RT_REF_LEAF, o, d, tmin, tmax, volume_key, scripted, n_scripted, t.found, t.best);
+            test_object<SIMPLE, MOTION>(s, t.cur & ~RT_REF_LEAF, o, d, tmin, tmax, volume_key, scripted, n_scripted, t.found, t.best, time);
             trav_pop(t, stack);
         }
     }
@@ -713,10 +744,25 @@ RT_DEV void csg_entry_of_interval(const RtDevScene &s, uint32_t csg_idx, f3 o, f
     }
 }
 
-RT_DEV void complete_hit(const RtDevScene &s, const Best &best, f3 o, f3 d, bool want_uv, HitRecord &h) {
+template <bool MOTION = false>
+RT_DEV void complete_hit(const RtDevScene &s, Best best, f3 o, f3 d, bool want_uv, HitRecord &h, float time = 0.0f) {
     uint32_t kind = (best.ref >> RT_KIND_SHIFT) & 7u, idx = best.ref & RT_INDEX_MASK;
     Surface sf;
     h.point = madd(d, best.t, o);
+    const f3 world_d = d;
+    MotionFrame frame;
+    bool moved = false;
+    uint32_t moving_object = 0;
+    if (MOTION && kind == RT_KIND_MOTION) {
+        frame = motion_frame(s, idx, time);
+        moving_object = s.motion_obj[idx];
+        o = frame_in(frame, o - frame.t);
+        d = frame_in(frame, d);
+        best.ref = frame.base;
+        kind = (best.ref >> RT_KIND_SHIFT) & 7u;
+        idx = best.ref & RT_INDEX_MASK;
+        moved = true;
+    }
     if (kind == RT_KIND_SPHERE) {
         sf = prim_surface(s, best.ref, 0, o, d, best.t, want_uv);
         h.object = s.sphere_obj[idx];
@@ -749,9 +795,13 @@ RT_DEV void complete_hit(const RtDevScene &s, const Best &best, f3 o, f3 d, bool
             sf.normal = -d;
         }
     }
+    if (MOTION && moved) {
+        sf.normal = frame_out(frame, sf.normal);
+        h.object = moving_object;
+    }
     h.u = sf.u; h.v = sf.v;
     h.material = sf.material;
-    if (dot(sf.normal, d) > 0.0f) { h.normal = -sf.normal; h.front = false; }
+    if (dot(sf.normal, world_d) > 0.0f) { h.normal = -sf.normal; h.front = false; }
     else { h.normal = sf.normal; h.front = true; }
 }
 

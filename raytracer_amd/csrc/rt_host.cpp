@@ -50,6 +50,7 @@ struct HostShape {
     std::vector<int> children;
     int base = -1;
     float density = 0;
+    float m_quat[4] = {1, 0, 0, 0}, m_trans[3] = {0, 0, 0};      // motion blur: unit quaternion (w, x, y, z), translation
     int parent = -1;        // CSG / volume that uses this shape, -1 if none
     int object = -1;        // scene object made of this shape, -1 if none
     uint32_t ref = RT_REF_NONE;
@@ -80,6 +81,7 @@ struct RtScene {
     uint32_t refill = 48;
     int node_min = -1;      // -1: chosen at render time from what the scene holds
     int node_format = RT_NODES_AUTO;
+    float query_time = 0.f;     // time of rt_first_hit / rt_intervals queries
     bool use_nodes16 = false;
     bool committed = false;
     std::vector<void *> device_allocs;
@@ -119,6 +121,67 @@ void xform(const HostShape &s, const float p[3], float out[3]) {
 // Bounding boxes: Primitives.swift:29-33 (sphere), :112-125 (cylinder, disk formula),
 // :163-180 (cuboid corners), :253-260 (quad corners); CSG.swift:21-23 (subtract = lhs),
 // :60-66 (union), :102-108 (intersection); ConstantDensityVolume.swift:21-23.
+// ---- where a moving object can be during [0, 1): Transform3D.boundingBoxForAnimation,
+// RayTracingKit/Transform.swift:93-154, in double precision.
+struct Quatd { double w, x, y, z; };
+Quatd quat_mul(Quatd a, Quatd b) {
+    return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+void quat_rotate(Quatd q, const double v[3], double out[3]) {
+    Quatd r = quat_mul(quat_mul(q, Quatd{0, v[0], v[1], v[2]}), Quatd{q.w, -q.x, -q.y, -q.z});
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void sweep_point(Quatd q, const double tr[3], const double p[3], double mn[3], double mx[3]) {
+    auto add = [&](const double v[3]) { for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], v[a]); mx[a] = std::max(mx[a], v[a]); } };
+    double p1[3], p2[3];
+    quat_rotate(q, p, p1);
+    for (int a = 0; a < 3; a++) p2[a] = p1[a] + tr[a];
+    add(p);
+    add(p2);
+    if (q.w == 1.0) return;
+    // each coordinate of p(t) = (sin((1-t)th) p + sin(t th) p1) / sin(th) + t tr has at most two
+    // stationary points in [0, 1]: A sin(t th) + B cos(t th) = C  (:99-136)
+    const double tau = 2 * 3.14159265358979323846264338327950288;
+    double th = 2 * std::acos(q.w), sin_th = std::sin(th), cos_th = std::cos(th);
+    auto norm_angle = [&](double x) { return x < 0 ? x + tau : (x >= tau ? x - tau : x); };
+    for (int a = 0; a < 3; a++) {
+        double A = th * sin_th * p[a], B = th * (cos_th * p[a] - p1[a]), C = tr[a] * sin_th;
+        double Z = C / std::sqrt(A * A + B * B);
+        if (!std::isfinite(Z) || std::fabs(Z) > 1) continue;
+        double phi = std::atan2(A, B), acos_z = std::acos(Z);
+        double ts[2] = {norm_angle(phi + acos_z) / th, norm_angle(phi - acos_z) / th};
+        for (double t : ts) {
+            if (!(std::isfinite(t) && t >= 0 && t <= 1)) continue;
+            double e[3];
+            for (int c = 0; c < 3; c++) e[c] = (std::sin((1 - t) * th) / sin_th) * p[c] + (std::sin(t * th) / sin_th) * p1[c] + t * tr[c];
+            add(e);
+        }
+    }
+}
+Box3 sweep_box(const float quat[4], const float trans[3], const Box3 &box) {
+    Quatd q{quat[0], quat[1], quat[2], quat[3]};
+    double tr[3] = {trans[0], trans[1], trans[2]};
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (q.w == 1.0) {
+        for (int a = 0; a < 3; a++) {
+            mn[a] = std::min((double)box.mn[a], box.mn[a] + tr[a]);
+            mx[a] = std::max((double)box.mx[a], box.mx[a] + tr[a]);
+        }
+    } else {
+        for (int i = 0; i < 8; i++) {
+            double p[3] = {(i & 1) ? box.mx[0] : box.mn[0], (i & 2) ? box.mx[1] : box.mn[1], (i & 4) ? box.mx[2] : box.mn[2]};
+            sweep_point(q, tr, p, mn, mx);
+        }
+    }
+    Box3 out;
+    for (int a = 0; a < 3; a++) {     // to float, outward
+        out.mn[a] = std::nextafter((float)mn[a], -INFINITY);
+        out.mx[a] = std::nextafter((float)mx[a], INFINITY);
+    }
+    return out;
+}
+
 Box3 shape_box(const RtScene &sc, int id) {
     const HostShape &s = sc.shapes[id];
     Box3 b;
@@ -162,6 +225,9 @@ Box3 shape_box(const RtScene &sc, int id) {
                 for (int a = 0; a < 3; a++) { b.mn[a] = std::max(b.mn[a], cb.mn[a]); b.mx[a] = std::min(b.mx[a], cb.mx[a]); }
             }
         }
+        break;
+    case RT_KIND_MOTION:
+        b = sweep_box(s.m_quat, s.m_trans, shape_box(sc, s.base));
         break;
     default:
         b = shape_box(sc, s.base);
@@ -411,6 +477,7 @@ RtDevRender make_render(const RtRenderConfig &rc, int w, int h) {
     r.spp = rc.samples_per_pixel; r.max_depth = rc.max_depth;
     r.first_sample = rc.first_sample;
     r.seed_lo = (uint32_t)rc.rng_seed; r.seed_hi = (uint32_t)(rc.rng_seed >> 32);
+    r.animated = 0;
     return r;
 }
 
@@ -634,6 +701,40 @@ int rt_shape_cdv(RtScene *sc, int base, float density) {
     return id;
 }
 
+int rt_shape_motion(RtScene *sc, int base, const RtMotion *m) {
+    if (!sc || !m || base < 0 || base >= (int)sc->shapes.size()) return fail(RT_ERR_INVALID, "bad base shape id");
+    const uint32_t bk = sc->shapes[base].kind;
+    if (bk == RT_KIND_CDV || bk == RT_KIND_MOTION)
+        return fail(RT_ERR_INVALID, "motion blur takes a primitive or a CSG shape");
+    if (sc->shapes[base].parent >= 0 || sc->shapes[base].object >= 0) return fail(RT_ERR_INVALID, "shape is already in use");
+    double len = 0;
+    for (int i = 0; i < 4; i++) len += (double)m->rotation[i] * m->rotation[i];
+    if (!(std::fabs(len - 1.0) < 1e-4) || !(m->rotation[0] >= 0.f))
+        return fail(RT_ERR_INVALID, "rotation must be a unit quaternion (w, x, y, z) with w >= 0");
+    HostShape s;
+    s.kind = RT_KIND_MOTION;
+    s.base = base;
+    memcpy(s.m_quat, m->rotation, 16);
+    memcpy(s.m_trans, m->translation, 12);
+    int id = push_shape(sc, std::move(s));
+    if (id >= 0) sc->shapes[base].parent = id;
+    return id;
+}
+
+int rt_shape_bounds(const RtScene *sc, int shape, float out_min_max[6]) {
+    if (!sc || !out_min_max || shape < 0 || shape >= (int)sc->shapes.size()) return fail(RT_ERR_INVALID, "bad shape id");
+    Box3 b = shape_box(*sc, shape);
+    for (int a = 0; a < 3; a++) { out_min_max[a] = b.mn[a]; out_min_max[3 + a] = b.mx[a]; }
+    return RT_OK;
+}
+
+int rt_scene_set_time(RtScene *sc, float time) {
+    if (!sc) return fail(RT_ERR_INVALID, "null scene");
+    if (!(time >= 0.f && time <= 1.f)) return fail(RT_ERR_INVALID, "time must lie in [0, 1]");
+    sc->query_time = time;
+    return RT_OK;
+}
+
 int rt_add_object(RtScene *sc, int shape) {
     if (!sc || shape < 0 || shape >= (int)sc->shapes.size()) return fail(RT_ERR_INVALID, "bad shape id");
     if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
@@ -735,6 +836,26 @@ int rt_scene_commit(RtScene *sc) {
         cdv.push_back(rec);
         cdv_obj.push_back(owner_object((int)id));
     }
+    std::vector<RtDevMotion> motion;
+    std::vector<uint32_t> motion_obj;
+    for (size_t id = 0; id < sc->shapes.size(); id++) {
+        HostShape &s = sc->shapes[id];
+        if (s.kind != RT_KIND_MOTION) continue;
+        RtDevMotion rec;
+        memset(&rec, 0, sizeof(rec));
+        rec.base = sc->shapes[s.base].ref;
+        // Quaternion.pow, Transform.swift:243-250: (cos(a t), v sin(a t) / sin(a)), a = acos(w)
+        double w = std::min(1.0, (double)s.m_quat[0]);
+        double a = std::acos(w), sin_a = std::sqrt(1 - w * w);
+        rec.qx = s.m_quat[1]; rec.qy = s.m_quat[2]; rec.qz = s.m_quat[3];
+        rec.half_angle = (float)a;
+        rec.inv_sin = (w == 1.0 || !std::isfinite(1.0 / sin_a)) ? 0.f : (float)(1.0 / sin_a);
+        if (rec.inv_sin == 0.f) rec.half_angle = 0.f;
+        rec.tx = s.m_trans[0]; rec.ty = s.m_trans[1]; rec.tz = s.m_trans[2];
+        s.ref = rt_make_ref(RT_KIND_MOTION, (uint32_t)motion.size());
+        motion.push_back(rec);
+        motion_obj.push_back(owner_object((int)id));
+    }
     // bulk spheres come after the described ones
     uint32_t first_bulk_object = (uint32_t)sc->objects.size();
     uint32_t first_bulk_sphere = (uint32_t)(spheres.size() / 4);
@@ -766,6 +887,7 @@ int rt_scene_commit(RtScene *sc) {
         it.box = shape_box(*sc, sc->objects[o]);
         pad_box(it.box);
         if (s.kind != RT_KIND_SPHERE) feat |= RT_FEAT_XPRIM;
+        if (s.kind == RT_KIND_MOTION) feat |= RT_FEAT_MOTION;
         bld.items.push_back(it);
     }
     for (size_t i = 0; i < n_bulk; i++) {
@@ -848,6 +970,8 @@ int rt_scene_commit(RtScene *sc) {
     if ((rc = upload(sc, csg_obj, &d.csg_obj)) < 0) return rc;
     if ((rc = upload(sc, cdv, &d.cdv)) < 0) return rc;
     if ((rc = upload(sc, cdv_obj, &d.cdv_obj)) < 0) return rc;
+    if ((rc = upload(sc, motion, &d.motion)) < 0) return rc;
+    if ((rc = upload(sc, motion_obj, &d.motion_obj)) < 0) return rc;
     if ((rc = upload(sc, sc->materials, &d.materials)) < 0) return rc;
     if ((rc = upload(sc, tex_desc, &d.textures)) < 0) return rc;
     if ((rc = upload(sc, texels, &d.texels)) < 0) return rc;
@@ -912,7 +1036,7 @@ int rt_first_hit(RtScene *sc, const float *rays_dev, int n, float tmin, float tm
                  void *stream) {
     if (!sc || n < 0 || (n > 0 && (!rays_dev || !out_dev))) return fail(RT_ERR_INVALID, "bad argument");
     if (!sc->committed) return fail(RT_ERR_STATE, "scene not committed");
-    hipError_t e = rt_launch_first_hit(sc->dev, sc->feat, rays_dev, n, tmin, tmax, volume_key, out_dev, as_stream(stream));
+    hipError_t e = rt_launch_first_hit(sc->dev, sc->feat, rays_dev, n, tmin, tmax, volume_key, sc->query_time, out_dev, as_stream(stream));
     return e == hipSuccess ? RT_OK : fail_hip(e, "first-hit launch");
 }
 
@@ -925,7 +1049,7 @@ int rt_intervals(RtScene *sc, int shape, const float *rays_dev, int n, const flo
     const HostShape &s = sc->shapes[shape];
     uint32_t object = s.object >= 0 ? (uint32_t)s.object : 0u;
     hipError_t e = rt_launch_intervals(sc->dev, s.ref, rays_dev, n, scripted_u_dev, n_scripted, volume_key, object,
-                                       events_dev, counts_dev, as_stream(stream));
+                                       sc->query_time, events_dev, counts_dev, as_stream(stream));
     return e == hipSuccess ? RT_OK : fail_hip(e, "intervals launch");
 }
 
@@ -955,6 +1079,7 @@ int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, i
     RtDevCamera cam;
     make_camera(*cc, width, height, cam);
     RtDevRender r = make_render(*rc, width, height);
+    r.animated = (sc->feat & RT_FEAT_MOTION) ? 1u : 0u;
     hipError_t e;
     if (pipeline == RT_PIPELINE_FUSED) {
         if (workspace_bytes < RT_FUSED_WORKSPACE) return fail(RT_ERR_INVALID, "workspace too small");

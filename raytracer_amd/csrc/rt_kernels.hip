@@ -30,14 +30,15 @@ RT_DEV uint32_t prefix_rank(uint64_t mask) {
 // ------------------------------------------------------------------ parity surface
 template <int FEAT>
 __global__ __launch_bounds__(RT_BLOCK) void k_first_hit(RtDevScene s, const float *rays, int n, float tmin, float tmax,
-                                                         uint64_t volume_key, RtHit *out) {
+                                                         uint64_t volume_key, float time, RtHit *out) {
     __shared__ uint32_t stack[RT_STACK_DEPTH * RT_BLOCK];
     int i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= n) return;
     const float *r = rays + 6 * (size_t)i;
     f3 o = mk3(r[0], r[1], r[2]), d = mk3(r[3], r[4], r[5]);
     Best b;
-    bool found = trace<!(FEAT & RT_FEAT_XPRIM)>(s, o, d, tmin, tmax, volume_key, nullptr, 0, stack + threadIdx.x, b);
+    constexpr bool MOTION = (FEAT & RT_FEAT_MOTION) != 0;
+    bool found = trace<!(FEAT & RT_FEAT_XPRIM), MOTION>(s, o, d, tmin, tmax, volume_key, nullptr, 0, stack + threadIdx.x, b, time);
     RtHit h;
     h.t = 0.f;
     h.point[0] = h.point[1] = h.point[2] = 0.f;
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_first_hit(RtDevScene s, const floa
     h.front_face = 0;
     if (found) {
         HitRecord hr;
-        complete_hit(s, b, o, d, true, hr);
+        complete_hit<MOTION>(s, b, o, d, true, hr, time);
         h.t = b.t;
         h.point[0] = hr.point.x; h.point[1] = hr.point.y; h.point[2] = hr.point.z;
         h.normal[0] = hr.normal.x; h.normal[1] = hr.normal.y; h.normal[2] = hr.normal.z;
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_first_hit(RtDevScene s, const floa
     out[i] = h;
 }
 
-RT_DEV void put_event(RtEvent *ev, int32_t &n, float t, bool is_exit, const Surface *sf, f3 o, f3 d) {
+RT_DEV void put_event(RtEvent *ev, int32_t &n, float t, bool is_exit, const Surface *sf, f3 o, f3 d,
+                      const MotionFrame *frame = nullptr) {
     if (n >= RT_MAX_EVENTS) return;
     RtEvent e;
     e.t = t;
@@ -73,7 +75,8 @@ RT_DEV void put_event(RtEvent *ev, int32_t &n, float t, bool is_exit, const Surf
     if (sf && finite(t)) {
         f3 p = madd(d, t, o);
         e.point[0] = p.x; e.point[1] = p.y; e.point[2] = p.z;
-        e.normal[0] = sf->normal.x; e.normal[1] = sf->normal.y; e.normal[2] = sf->normal.z;
+        f3 nn = frame ? frame_out(*frame, sf->normal) : sf->normal;
+        e.normal[0] = nn.x; e.normal[1] = nn.y; e.normal[2] = nn.z;
         e.uv[0] = sf->u; e.uv[1] = sf->v;
         e.material_offset = sf->material;
     }
@@ -84,22 +87,34 @@ RT_DEV void put_event(RtEvent *ev, int32_t &n, float t, bool is_exit, const Surf
 // Impl/RenderableImpl.h as a list.
 __global__ __launch_bounds__(RT_BLOCK) void k_intervals(RtDevScene s, uint32_t ref, const float *rays, int n,
                                                          const float *scripted, int n_scripted, uint64_t volume_key,
-                                                         uint32_t object, RtEvent *events, int32_t *counts) {
+                                                         uint32_t object, float time, RtEvent *events, int32_t *counts) {
     int i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= n) return;
     const float *r = rays + 6 * (size_t)i;
     f3 o = mk3(r[0], r[1], r[2]), d = mk3(r[3], r[4], r[5]);
+    const f3 wo = o, wd = d;           // events report world-space points
     RtEvent *ev = events + (size_t)i * RT_MAX_EVENTS;
     int32_t cnt = 0;
     uint32_t kind = (ref >> RT_KIND_SHIFT) & 7u, idx = ref & RT_INDEX_MASK;
+    MotionFrame frame;
+    const MotionFrame *fr = nullptr;
+    if (kind == RT_KIND_MOTION) {
+        frame = motion_frame(s, idx, time);
+        fr = &frame;
+        o = frame_in(frame, o - frame.t);
+        d = frame_in(frame, d);
+        ref = frame.base;
+        kind = (ref >> RT_KIND_SHIFT) & 7u;
+        idx = ref & RT_INDEX_MASK;
+    }
     if (kind <= RT_KIND_QUAD) {
         Span sp = prim_span(s, ref, o, d);
         if (span_valid(sp)) {
             Surface a, b;
             if (finite(sp.t0)) a = prim_surface(s, ref, sp.tag0, o, d, sp.t0, true);
             if (finite(sp.t1)) b = prim_surface(s, ref, sp.tag1, o, d, sp.t1, true);
-            put_event(ev, cnt, sp.t0, false, &a, o, d);
-            put_event(ev, cnt, sp.t1, true, &b, o, d);
+            put_event(ev, cnt, sp.t0, false, &a, wo, wd, fr);
+            put_event(ev, cnt, sp.t1, true, &b, wo, wd, fr);
         }
     } else if (kind == RT_KIND_CSG) {
         CsgIter it;
@@ -108,7 +123,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intervals(RtDevScene s, uint32_t r
             uint32_t code = it.tag | (it.leaf << 3);
             Surface sf;
             if (finite(it.t)) sf = csg_surface(s, idx, code, o, d, it.t, true);
-            put_event(ev, cnt, it.t, it.is_exit, &sf, o, d);
+            put_event(ev, cnt, it.t, it.is_exit, &sf, wo, wd, fr);
         }
     } else {
         // ConstantDensityVolume<Impl>::HitEnumerator, RenderableImpl.h:727-802
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_progressive_present(const float *p
 // (Camera.swift:114-122) instead of zeroing it (Shaders.metal:127-128).
 template <int FEAT>
 RT_DEV bool shade_path(const RtDevScene &s, uint32_t background, uint32_t max_depth, bool found, const Best &b,
-                       f3 &o, f3 &d, f3 &thr, f3 &rad, uint32_t &depth, Pcg &g) {
+                       f3 &o, f3 &d, f3 &thr, f3 &rad, uint32_t &depth, Pcg &g, float time = 0.0f) {
     if (!found) {
         rad = rad + thr * background_color(background, d);
         return false;
@@ -252,7 +267,7 @@ RT_DEV bool shade_path(const RtDevScene &s, uint32_t background, uint32_t max_de
             h.u = sf.u; h.v = sf.v;
         }
     } else {
-        complete_hit(s, b, o, d, maybe_uv, h);
+        complete_hit<(FEAT & RT_FEAT_MOTION) != 0>(s, b, o, d, maybe_uv, h, time);
         m = load_material(s, h.material);
     }
     f3 emitted, atten, nd;
@@ -305,11 +320,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_raygen(WfQueues q, RtDevCamera 
         Pcg g = sample_stream(seed, rc.first_sample + sidx, x, y);
         f3 o, d;
         camera_ray(cam, x, y, g, o, d);
+        float time = rc.animated ? rnd(g) : 0.f;     // Camera.swift:89: after the ray, one per sample
         uint32_t chunk = i >> 8;
         uint32_t slot = (chunk % RT_WF_SHARDS) * q.shard_cap + (chunk / RT_WF_SHARDS) * 256u + (i & 255u);
         q.ray_o[0][slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
         q.ray_d[0][slot] = make_float4(d.x, d.y, d.z, __uint_as_float(0u));
-        q.thr[0][slot] = make_float4(1.f, 1.f, 1.f, 0.f);
+        q.thr[0][slot] = make_float4(1.f, 1.f, 1.f, time);
         q.rad[0][slot] = make_float4(0.f, 0.f, 0.f, 0.f);
         q.rng[0][slot] = make_uint4((uint32_t)g.state, (uint32_t)(g.state >> 32), (uint32_t)g.inc, (uint32_t)(g.inc >> 32));
     }
@@ -331,8 +347,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_extend(RtDevScene s, WfQueues q
             key = ((uint64_t)r.y << 32) | r.x;
         }
         Best b;
-        bool found = trace<!(FEAT & RT_FEAT_XPRIM)>(s, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), RT_T_MIN, RT_INF, key,
-                                                   nullptr, 0, stack + threadIdx.x, b);
+        float time = 0.f;
+        if (FEAT & RT_FEAT_MOTION) time = q.thr[cur][i].w;
+        bool found = trace<!(FEAT & RT_FEAT_XPRIM), (FEAT & RT_FEAT_MOTION) != 0>(s, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), RT_T_MIN,
+                                                                                RT_INF, key, nullptr, 0, stack + threadIdx.x, b, time);
         q.hit[i] = make_float4(b.t, __uint_as_float(found ? b.ref : RT_REF_NONE), __uint_as_float(b.code), 0.f);
     }
 }
@@ -353,6 +371,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_shade(RtDevScene s, WfQueues q,
         uint32_t j = jb + threadIdx.x, i = shard * q.shard_cap + j;
         bool survive = false;
         f3 o, d, thr, rad;
+        float time = 0.f;
         uint32_t pid = 0, depth = 0;
         Pcg g;
         g.state = g.inc = 0;
@@ -361,12 +380,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_shade(RtDevScene s, WfQueues q,
             uint4 rr = q.rng[cur][i];
             o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z);
             thr = mk3(t4.x, t4.y, t4.z); rad = mk3(r4.x, r4.y, r4.z);
+            time = t4.w;
             pid = __float_as_uint(ro.w); depth = __float_as_uint(rd.w);
             g.state = ((uint64_t)rr.y << 32) | rr.x;
             g.inc = ((uint64_t)rr.w << 32) | rr.z;
             Best b;
             b.t = h4.x; b.ref = __float_as_uint(h4.y); b.code = __float_as_uint(h4.z);
-            survive = shade_path<FEAT>(s, background, max_depth, b.ref != RT_REF_NONE, b, o, d, thr, rad, depth, g);
+            survive = shade_path<FEAT>(s, background, max_depth, b.ref != RT_REF_NONE, b, o, d, thr, rad, depth, g, time);
             if (!survive) q.sample_rad[pid] = make_float4(rad.x, rad.y, rad.z, 0.f);
         }
         uint64_t mask = __ballot(survive);
@@ -384,7 +404,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_shade(RtDevScene s, WfQueues q,
             uint32_t k = shard * q.shard_cap + block_base + before + prefix_rank(mask);
             q.ray_o[nxt][k] = make_float4(o.x, o.y, o.z, __uint_as_float(pid));
             q.ray_d[nxt][k] = make_float4(d.x, d.y, d.z, __uint_as_float(depth));
-            q.thr[nxt][k] = make_float4(thr.x, thr.y, thr.z, 0.f);
+            q.thr[nxt][k] = make_float4(thr.x, thr.y, thr.z, time);
             q.rad[nxt][k] = make_float4(rad.x, rad.y, rad.z, 0.f);
             q.rng[nxt][k] = make_uint4((uint32_t)g.state, (uint32_t)(g.state >> 32), (uint32_t)g.inc, (uint32_t)(g.inc >> 32));
         }
@@ -456,6 +476,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, RtDevCame
         f3 thr = mk3(0, 0, 0), rad = mk3(0, 0, 0);
         uint32_t depth = 0, pix = 0;
         uint64_t key = 0;
+        float time = 0.f;               // the sample's time; only scenes with moving objects draw one
         Pcg g;
         g.state = g.inc = 0;
         Trav t;
@@ -467,7 +488,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, RtDevCame
             RT_PROF_BEGIN();
             const bool shading = has_path && t.cur == RT_REF_NONE;
             if (has_path && t.cur == RT_REF_NONE) {
-                bool alive = shade_path<FEAT>(s, cam.background, rc.max_depth, t.found, t.best, o, d, thr, rad, depth, g);
+                bool alive = shade_path<FEAT>(s, cam.background, rc.max_depth, t.found, t.best, o, d, thr, rad, depth, g, time);
                 if (alive) {
                     start = true;
                 } else {
@@ -492,6 +513,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, RtDevCame
                         if (x < rc.width && y < rc.height) {
                             g = sample_stream(seed, rc.first_sample + s_begin + (k >> 6), x, y);
                             camera_ray(cam, x, y, g, o, d);
+                            if (FEAT & RT_FEAT_MOTION) time = rnd(g);
                             thr = mk3(1, 1, 1);
                             rad = mk3(0, 0, 0);
                             depth = 0;
@@ -531,7 +553,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, RtDevCame
                 RT_PROF_BEGIN();
                 const bool at_leaf = (t.cur & RT_REF_LEAF) && t.cur != RT_REF_NONE;
                 if (at_leaf) {
-                    test_object<SIMPLE>(s, t.cur & ~RT_REF_LEAF, t.o, t.d, RT_T_MIN, RT_INF, key, nullptr, 0, t.found, t.best);
+                    test_object<SIMPLE, (FEAT & RT_FEAT_MOTION) != 0>(s, t.cur & ~RT_REF_LEAF, t.o, t.d, RT_T_MIN, RT_INF, key, nullptr, 0, t.found, t.best, time);
                     trav_pop(t, stack);
                 }
                 RT_PROF_END(3, at_leaf);
@@ -590,20 +612,22 @@ void rt_wavefront_carve(void *workspace, uint32_t capacity, RtWavefrontBuffers &
 static inline int blocks_for(size_t n) { return (int)((n + RT_BLOCK - 1) / RT_BLOCK); }
 
 hipError_t rt_launch_first_hit(const RtDevScene &s, uint32_t feat, const float *rays, int n, float tmin, float tmax,
-                               uint64_t volume_key, RtHit *out, hipStream_t stream) {
+                               uint64_t volume_key, float time, RtHit *out, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    if (feat & RT_FEAT_XPRIM)
-        k_first_hit<3><<<blocks_for(n), RT_BLOCK, 0, stream>>>(s, rays, n, tmin, tmax, volume_key, out);
+    if (feat & RT_FEAT_MOTION)
+        k_first_hit<7><<<blocks_for(n), RT_BLOCK, 0, stream>>>(s, rays, n, tmin, tmax, volume_key, time, out);
+    else if (feat & RT_FEAT_XPRIM)
+        k_first_hit<3><<<blocks_for(n), RT_BLOCK, 0, stream>>>(s, rays, n, tmin, tmax, volume_key, time, out);
     else
-        k_first_hit<2><<<blocks_for(n), RT_BLOCK, 0, stream>>>(s, rays, n, tmin, tmax, volume_key, out);
+        k_first_hit<2><<<blocks_for(n), RT_BLOCK, 0, stream>>>(s, rays, n, tmin, tmax, volume_key, time, out);
     return hipGetLastError();
 }
 
 hipError_t rt_launch_intervals(const RtDevScene &s, uint32_t ref, const float *rays, int n, const float *scripted,
-                               int n_scripted, uint64_t volume_key, uint32_t object, RtEvent *events, int32_t *counts,
-                               hipStream_t stream) {
+                               int n_scripted, uint64_t volume_key, uint32_t object, float time, RtEvent *events,
+                               int32_t *counts, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    k_intervals<<<blocks_for(n), RT_BLOCK, 0, stream>>>(s, ref, rays, n, scripted, n_scripted, volume_key, object, events, counts);
+    k_intervals<<<blocks_for(n), RT_BLOCK, 0, stream>>>(s, ref, rays, n, scripted, n_scripted, volume_key, object, time, events, counts);
     return hipGetLastError();
 }
 
@@ -686,11 +710,13 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
         int grid = std::min(blocks_for((size_t)npix * batch), device_cus() * 8);
         grid = (grid + (int)RT_WF_SHARDS - 1) / (int)RT_WF_SHARDS * (int)RT_WF_SHARDS;
         hipError_t e;
-        switch (feat & 3u) {
+        switch (feat & 7u) {
         case 0: e = wavefront_batch<0>(s, cam, r, batch, q, accum, stream, timer, grid); break;
         case 1: e = wavefront_batch<1>(s, cam, r, batch, q, accum, stream, timer, grid); break;
         case 2: e = wavefront_batch<2>(s, cam, r, batch, q, accum, stream, timer, grid); break;
-        default: e = wavefront_batch<3>(s, cam, r, batch, q, accum, stream, timer, grid); break;
+        case 3: e = wavefront_batch<3>(s, cam, r, batch, q, accum, stream, timer, grid); break;
+        case 5: e = wavefront_batch<5>(s, cam, r, batch, q, accum, stream, timer, grid); break;
+        default: e = wavefront_batch<7>(s, cam, r, batch, q, accum, stream, timer, grid); break;
         }
         if (e != hipSuccess) return e;
     }
@@ -733,13 +759,15 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
     const bool n16 = (knobs & 0x20000u) != 0 && s.nodes16 != nullptr;
 #define RT_FUSED(F, ST, W) (n16 ? fused_launch<F, ST, W, true>(s, cam, rc, accum, counter, knobs, stream, timer) \
                                 : fused_launch<F, ST, W, false>(s, cam, rc, accum, counter, knobs, stream, timer))
-    switch (feat & 3u) {
+    switch (feat & 7u) {
     case 0:
         if (bvh_depth <= 16) return RT_FUSED(0, 16, 8);
         return RT_FUSED(0, RT_STACK_DEPTH, 5);
     case 1: return RT_FUSED(1, RT_STACK_DEPTH, 4);
     case 2: return RT_FUSED(2, RT_STACK_DEPTH, 5);
-    default: return RT_FUSED(3, RT_STACK_DEPTH, 4);
+    case 3: return RT_FUSED(3, RT_STACK_DEPTH, 4);
+    case 5: return RT_FUSED(5, RT_STACK_DEPTH, 4);
+    default: return RT_FUSED(7, RT_STACK_DEPTH, 4);
     }
 #undef RT_FUSED
 }

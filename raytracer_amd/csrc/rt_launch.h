@@ -14,6 +14,7 @@
 enum : uint32_t {
     RT_FEAT_XPRIM = 1u,      // anything other than plain spheres in the BVH
     RT_FEAT_TEXTURE = 2u,    // image or Perlin materials
+    RT_FEAT_MOTION = 4u,     // moving objects: every sample draws a time (implies RT_FEAT_XPRIM)
 };
 
 // HIP events around every launch of the render loop's dominant kernel, on the stream the
@@ -69,10 +70,10 @@ size_t rt_wavefront_bytes(uint32_t capacity);
 void rt_wavefront_carve(void *workspace, uint32_t capacity, RtWavefrontBuffers &out);
 
 hipError_t rt_launch_first_hit(const RtDevScene &s, uint32_t feat, const float *rays, int n, float tmin, float tmax,
-                               uint64_t volume_key, RtHit *out, hipStream_t stream);
+                               uint64_t volume_key, float time, RtHit *out, hipStream_t stream);
 hipError_t rt_launch_intervals(const RtDevScene &s, uint32_t ref, const float *rays, int n, const float *scripted,
-                               int n_scripted, uint64_t volume_key, uint32_t object, RtEvent *events, int32_t *counts,
-                               hipStream_t stream);
+                               int n_scripted, uint64_t volume_key, uint32_t object, float time, RtEvent *events,
+                               int32_t *counts, hipStream_t stream);
 hipError_t rt_launch_camera_rays(const RtDevCamera &cam, const RtDevRender &rc, int x0, int y0, int w, int h,
                                  float *rays_out, hipStream_t stream);
 hipError_t rt_launch_resolve(const float *accum, float inv_samples, int width, int height, uint8_t *rgbx, hipStream_t stream);

@@ -32,6 +32,7 @@ enum RtPrimKind : uint32_t {
     RT_KIND_QUAD = 3,
     RT_KIND_CSG = 4,
     RT_KIND_CDV = 5,
+    RT_KIND_MOTION = 6,
 };
 
 #ifndef RT_STACK_DEPTH
@@ -52,6 +53,15 @@ struct RtDevCsg {
 struct RtDevCdv {
     uint32_t base;                      // primitive or CSG reference
     float neg_inv_density;
+};
+
+// MotionBlur (RayTracingKit/Hittable.swift:528-555): `base` seen through transform.pow(time).
+struct RtDevMotion {
+    uint32_t base;                      // primitive or CSG reference
+    float qx, qy, qz;                   // vector part of the unit quaternion (w = cos(half_angle) >= 0)
+    float half_angle, inv_sin;          // acos(w) and 1 / sin(acos(w)); inv_sin = 0 for the identity rotation
+    float tx, ty, tz;
+    uint32_t pad[3];
 };
 
 struct RtDevTexture {
@@ -84,6 +94,8 @@ struct RtDevScene {
     const uint32_t *csg_obj;
     const RtDevCdv *cdv;
     const uint32_t *cdv_obj;
+    const RtDevMotion *motion;
+    const uint32_t *motion_obj;
     const float *materials;        // n x 8
     const RtDevTexture *textures;
     const uint32_t *texels;
@@ -108,4 +120,5 @@ struct RtDevRender {
     uint32_t spp, max_depth;
     uint32_t first_sample;
     uint32_t seed_lo, seed_hi;
+    uint32_t animated;       // 1 when the scene holds moving objects: every sample draws a time after its ray
 };

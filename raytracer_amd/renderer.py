@@ -84,6 +84,17 @@ class NativeScene:
     def shape_cdv(self, base, density):
         return check(lib.rt_shape_cdv(self.h, base, density))
 
+    def shape_motion(self, base, rec):
+        return check(lib.rt_shape_motion(self.h, base, C.byref(rec)))
+
+    def bounds(self, shape):
+        out = (C.c_float * 6)()
+        check(lib.rt_shape_bounds(self.h, shape, out))
+        return np.array(out[:3]), np.array(out[3:])
+
+    def set_time(self, time):
+        check(lib.rt_scene_set_time(self.h, float(time)))
+
     def add_object(self, shape):
         return check(lib.rt_add_object(self.h, shape))
 

@@ -532,6 +532,61 @@ class ConstantDensityVolume(Renderable):
         return encoder.sink.shape_cdv(self.base.as_impl(encoder), self.density)
 
 
+class MotionBlur(Renderable):
+    """RayTracingKit/Hittable.swift:528-555: `base` seen through transform.pow(time) for the
+    sample's time in [0, 1).  The quaternion is kept with w >= 0 like the Kit's
+    (Transform.swift:198-206), so the motion takes the short way round."""
+
+    def __init__(self, transform, base):
+        self.transform = transform
+        self.base = base
+
+    def pow(self, t):
+        """transform.pow(t), Transform.swift:82-84,243-250."""
+        q = self.transform.rotation
+        w, v = float(q.r), q.v.astype(np.float64)
+        if w < 0:
+            w, v = -w, -v
+        if w >= 1.0:
+            rot = Quat.identity()
+        else:
+            a = math.acos(w)
+            k = math.sin(a * t) / math.sqrt(1 - w * w)
+            rot = Quat(v[0] * k, v[1] * k, v[2] * k, math.cos(a * t))
+        return Transform(rot, self.transform.translation.astype(np.float64) * t)
+
+    @property
+    def bounding_box(self):
+        """A box around the base box's corners at 129 times, widened by the largest step
+        between them: encloses the exact sweep (Transform.swift:93-154, which the native
+        library restates for the BVH; rt_shape_bounds returns that one)."""
+        base = self.base.bounding_box
+        corners = [np.array([(base.max if i & 1 else base.min)[0], (base.max if i & 2 else base.min)[1],
+                             (base.max if i & 4 else base.min)[2]], dtype=np.float64) for i in range(8)]
+        b = AABB()
+        step = 0.0
+        prev = None
+        for k in range(129):
+            tr = self.pow(k / 128.0)
+            pts = [tr.act(c) for c in corners]
+            if prev is not None:
+                step = max(step, max(float(np.linalg.norm(p - q)) for p, q in zip(pts, prev)))
+            prev = pts
+            for p in pts:
+                b.add(p)
+        b.min = b.min - np.float32(step)
+        b.max = b.max + np.float32(step)
+        return b
+
+    def as_impl(self, encoder):
+        q = self.transform.rotation
+        w, v = float(q.r), [float(c) for c in q.v]
+        if w < 0:
+            w, v = -w, [-c for c in v]
+        rec = abi.RtMotion((C.c_float * 4)(w, *v), (C.c_float * 3)(*[float(c) for c in self.transform.translation]))
+        return encoder.sink.shape_motion(self.base.as_impl(encoder), rec)
+
+
 # ---------------------------------------------------------------------------- config
 class CameraConfig:
     """Config.swift:9-70: plain fields plus the orbit accessor the app's sliders drive."""

@@ -13,8 +13,8 @@ from . import abi
 from .scene import (CameraConfig, ColoredEmissive, ColoredIsotropic, ColoredLambertian, ColoredMetal,
                     ConstantDensityVolume, Cuboid, Cylinder, Dielectric, ImageTexture, Intersection,
                     PerlinNoiseLambertian, PerlinNoiseTexture, Quad, Scene, Sphere, Subtract,
-                    TexturedLambertian, Transform, Union, WyRand, u64_to_unit, wyrand_block)
-from .simd import vec3
+                    TexturedLambertian, Transform, Union, WyRand, u64_to_unit, wyrand_block, MotionBlur)
+from .simd import Quat, normalize, vec3
 
 T = Transform
 
@@ -202,6 +202,26 @@ def random_spheres(seed=1):
     return Scene(cam, objs)
 
 
+def bouncing_spheres(seed=1):
+    """The random-spheres workload with its lambertian spheres in motion: each moves
+    straight up by up to half a unit over the exposure, a few metal ones also spin about
+    a tilted axis while they drift."""
+    base = random_spheres(seed)
+    rng = WyRand(seed ^ 0xB0B)
+    objs = []
+    for k, obj in enumerate(base.objects):
+        small = isinstance(obj, Sphere) and obj.radius < 0.5
+        if small and isinstance(obj.material, ColoredLambertian):
+            objs.append(MotionBlur(Transform.translate(0, 0.5 * rng.uniform(), 0), obj))
+        elif small and isinstance(obj.material, ColoredMetal) and k % 3 == 0:
+            spin = Transform(Quat.from_angle_axis(rng.uniform(0.2, 1.2), normalize(vec3(0.3, 1.0, 0.2))),
+                             (0.3 * rng.uniform(), 0, 0.3 * rng.uniform()))
+            objs.append(MotionBlur(spin, obj))
+        else:
+            objs.append(obj)
+    return Scene(base.camera, objs)
+
+
 def cornell_smoke():
     """Cornell box with two smoke-filled boxes: six quads spanning 555^3, an emissive
     ceiling quad, two rotated cuboids wrapped in constant-density volumes."""
@@ -302,6 +322,7 @@ WORKLOADS = {
     "cfg3_cornell_smoke_1080p": (cornell_smoke, 1920, 1080, 4096, 50, 3),
     "cfg4_csg_textured_1080p": (csg_textured, 1920, 1080, 2048, 50, 7),
     "cfg5_sphere_cloud_4k": (SphereCloud, 3840, 2160, 8192, 50, 42),
+    "f2_bouncing_spheres_1080p": (bouncing_spheres, 1920, 1080, 256, 50, 1),
 }
 
 

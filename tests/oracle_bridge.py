@@ -70,7 +70,7 @@ def lib():
         L.orc_last_error.restype = C.c_char_p
         for name in ("orc_scene_destroy", "orc_add_material", "orc_add_texture_rgb8", "orc_add_perlin",
                      "orc_shape_sphere", "orc_shape_cylinder", "orc_shape_cuboid", "orc_shape_quad",
-                     "orc_shape_csg", "orc_shape_cdv", "orc_add_object", "orc_commit", "orc_enumerate",
+                     "orc_shape_csg", "orc_shape_cdv", "orc_shape_motion", "orc_shape_bounds", "orc_add_object", "orc_commit", "orc_enumerate",
                      "orc_first_hit", "orc_render"):
             getattr(L, name).argtypes = None
         _lib = L
@@ -142,6 +142,20 @@ class OracleScene:
 
     def shape_cdv(self, base, density):
         return _check(self.L.orc_shape_cdv(self.h, C.c_int(base), C.c_float(density)))
+
+    def shape_motion(self, base, rec):
+        q = (C.c_double * 4)(*[float(x) for x in rec.rotation])
+        t = (C.c_double * 3)(*[float(x) for x in rec.translation])
+        return _check(self.L.orc_shape_motion(self.h, C.c_int(base), q, t))
+
+    def bounds(self, shape):
+        out = (C.c_double * 6)()
+        _check(self.L.orc_shape_bounds(self.h, C.c_int(shape), out))
+        return np.array(out[:3]), np.array(out[3:])
+
+    def set_time(self, time):
+        self.L.orc_set_query_time.restype = None
+        self.L.orc_set_query_time(self.h, C.c_double(time))
 
     def add_object(self, shape):
         return _check(self.L.orc_add_object(self.h, C.c_int(shape)))
