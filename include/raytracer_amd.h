@@ -76,6 +76,9 @@ enum RtMaterialKind {
     rt_material_kind_dielectric,
     rt_material_kind_emissive_colored,
     rt_material_kind_isotropic_colored,
+    /* RayTracingKit materials over an arbitrary Texture (Material.swift:17-41,75-93): no Metal counterpart */
+    rt_material_kind_lambertian_kit_texture,
+    rt_material_kind_emissive_kit_texture,
 };
 
 /* Materials.h:30-36: the Metal resource id becomes the id rt_add_texture_rgb8 returned. */
@@ -197,6 +200,35 @@ int rt_add_material(RtScene *, const void *record, size_t size);
 /* TextureLoader.load (Texture.swift:20-41): 8-bit RGB, rows top to bottom; texture
  * coordinate v = 0 is the bottom row as with the reference's bottom-left origin. */
 int rt_add_texture_rgb8(RtScene *, int width, int height, const uint8_t *rgb);
+
+/* ---- RayTracingKit textures (Texture.swift): solid, checker over two textures, bilinear
+ * image window, noise, marble.  A material of kind rt_material_kind_lambertian_kit_texture /
+ * rt_material_kind_emissive_kit_texture names one by the handle rt_add_kit_texture returned. */
+typedef struct RtKitPerlin {             /* PerlinNoise, Texture.swift:166-182 */
+    float vectors[256][3];               /* components in [-1, 1], not normalised */
+    uint8_t perm_x[256], perm_y[256], perm_z[256];
+} RtKitPerlin;
+enum RtKitTextureKind {
+    RT_KIT_TEXTURE_SOLID = 0,            /* SolidColor, :13-25 */
+    RT_KIT_TEXTURE_CHECKER = 1,          /* CheckerTexture, :27-51: even / odd are texture handles */
+    RT_KIT_TEXTURE_IMAGE = 2,            /* ImageTexture, :53-120: bilinear, window, mirrored, wrapped or clamped */
+    RT_KIT_TEXTURE_NOISE = 3,            /* NoiseTexture, :136-149 */
+    RT_KIT_TEXTURE_MARBLE = 4            /* Marble, :151-164 */
+};
+typedef struct RtKitTexture {
+    uint32_t kind;
+    float color[3];                      /* solid */
+    float scale;                         /* checker, noise, marble */
+    int32_t even, odd;                   /* checker */
+    int32_t image;                       /* image: handle of rt_add_texture_rgb8 (rows top to bottom) */
+    int32_t origin_x, origin_y;          /* image: first texel column / row (:55-56) */
+    int32_t width, height;               /* image: window size; negative = runs towards smaller indices (:72-75) */
+    uint32_t wrap_x, wrap_y;             /* image: wrap (1) or clamp (0) outside the window (:103-120) */
+    int32_t perlin;                      /* noise, marble: handle of rt_add_kit_perlin */
+} RtKitTexture;
+typedef struct { uint32_t kind; uint32_t texture; } RtKitTexturedMaterial;
+int rt_add_kit_perlin(RtScene *, const RtKitPerlin *);     /* -> perlin handle */
+int rt_add_kit_texture(RtScene *, const RtKitTexture *);   /* -> texture handle */
 
 /* Renderable.asImpl (Primitives.swift:39-42,133-145,186-193,266-274): returns a shape id. */
 int rt_shape_sphere(RtScene *, const RtSphere *);

@@ -214,6 +214,8 @@ struct Scene {
     std::vector<OrcMaterial> materials;
     std::vector<Image> images;
     std::vector<OrcPerlin> perlins;
+    std::vector<OrcKitTexture> kit_textures;
+    std::vector<OrcKitPerlin> kit_perlins;
     std::vector<BvhNode> nodes;
     int root = -1;          // node index, or ~object when there is a single object
     bool committed = false;
@@ -933,6 +935,80 @@ template <class R> V3<R> perlin_color(const OrcPerlin &tex, V3<R> point) {
     return c0 + (c1 - c0) * t;
 }
 
+// ---- RayTracingKit textures, Texture.swift
+// PerlinNoise, :184-223: Hermite weights, cell from Int() (truncation), fraction from floor().
+template <class R> R kit_noise(const OrcKitPerlin &n, V3<R> p) {
+    R u = p.x - std::floor(p.x), v = p.y - std::floor(p.y), w = p.z - std::floor(p.z);
+    auto hermitian = [](R x) { return x * x * (3 - 2 * x); };
+    R uu = hermitian(u), vv = hermitian(v), ww = hermitian(w);
+    long i = (long)p.x, j = (long)p.y, k = (long)p.z;
+    R result = 0;
+    for (int di = 0; di < 2; di++)
+        for (int dj = 0; dj < 2; dj++)
+            for (int dk = 0; dk < 2; dk++) {
+                int index = n.perm_x[(i + di) & 255] ^ n.perm_y[(j + dj) & 255] ^ n.perm_z[(k + dk) & 255];
+                R weight = (di == 0 ? 1 - uu : uu) * (dj == 0 ? 1 - vv : vv) * (dk == 0 ? 1 - ww : ww);
+                V3<R> g(R(n.vectors[index][0]), R(n.vectors[index][1]), R(n.vectors[index][2]));
+                result += weight * dot(g, V3<R>(u - R(di), v - R(dj), w - R(dk)));
+            }
+    return result;
+}
+template <class R> R kit_noise_turbulence(const OrcKitPerlin &n, V3<R> point, int turbulence) {
+    R accum = 0, weight = 1;
+    V3<R> p = point;
+    for (int t = 0; t < turbulence; t++) {
+        accum += weight * kit_noise<R>(n, p);
+        weight *= R(0.5);
+        p = p * R(2);
+    }
+    return accum;
+}
+inline long kit_clip(long index, long size, bool wrap) {                    // :103-120
+    if (index < 0) return wrap ? size + (index % size) : 0;
+    if (index >= size) return wrap ? index % size : size - 1;
+    return index;
+}
+template <class R> V3<R> kit_texture_color(const Scene &sc, int id, R u, R v, V3<R> point) {
+    const OrcKitTexture &t = sc.kit_textures[(size_t)id];
+    switch (t.kind) {
+    case 1: {                                                                // CheckerTexture, :44-50
+        R inv_scale = R(1) / R(t.scale);
+        long xi = (long)std::floor(inv_scale * point.x), yi = (long)std::floor(inv_scale * point.y), zi = (long)std::floor(inv_scale * point.z);
+        bool is_even = (xi + yi + zi) % 2 == 0;
+        return kit_texture_color<R>(sc, is_even ? t.even : t.odd, u, v, point);
+    }
+    case 2: {                                                                // ImageTexture, :80-101
+        const Image &im = sc.images[(size_t)t.image];
+        long width = std::labs((long)t.width), height = std::labs((long)t.height);
+        bool invert_x = t.width < 0, invert_y = t.height < 0;
+        auto pixel = [&](long i, long j) {
+            long ix = t.origin_y + kit_clip(i, height, t.wrap_y != 0) * (invert_y ? -1 : +1);
+            long jx = t.origin_x + kit_clip(j, width, t.wrap_x != 0) * (invert_x ? -1 : +1);
+            ix = std::min<long>(std::max<long>(ix, 0), im.h - 1);           // the reference asserts here
+            jx = std::min<long>(std::max<long>(jx, 0), im.w - 1);
+            const uint8_t *px = &im.rgb[3 * ((size_t)ix * im.w + (size_t)jx)];
+            return V3<R>(R(px[0]), R(px[1]), R(px[2])) / R(255);
+        };
+        R i = v * R(height) - R(0.5), j = u * R(width) - R(0.5);
+        long i1 = (long)std::floor(i), i2 = i1 + 1, j1 = (long)std::floor(j), j2 = j1 + 1;
+        R a = i - R(i1), b = j - R(j1);
+        V3<R> c1 = pixel(i1, j1) * (1 - b) + pixel(i1, j2) * b;
+        V3<R> c2 = pixel(i2, j1) * (1 - b) + pixel(i2, j2) * b;
+        return c1 * (1 - a) + c2 * a;
+    }
+    case 3: {                                                                // NoiseTexture, :145-148
+        R grey = std::fabs(kit_noise_turbulence<R>(sc.kit_perlins[(size_t)t.perlin], R(t.scale) * point, 7));
+        return V3<R>(grey, grey, grey);
+    }
+    case 4: {                                                                // Marble, :160-163
+        R grey = (1 + std::sin(R(t.scale) * point.z + 10 * kit_noise_turbulence<R>(sc.kit_perlins[(size_t)t.perlin], point, 7))) * R(0.5);
+        return V3<R>(grey, grey, grey);
+    }
+    default:
+        return V3<R>(R(t.color[0]), R(t.color[1]), R(t.color[2]));
+    }
+}
+
 template <class R> V3<R> material_color(const Scene &sc, const OrcMaterial &m, const HitInfo<R> &hit) {
     switch (m.kind) {
     case orc_material_kind_lambertian_textured:
@@ -941,6 +1017,9 @@ template <class R> V3<R> material_color(const Scene &sc, const OrcMaterial &m, c
     case orc_material_kind_lambertian_perlin_noise:
     case orc_material_kind_metal_perlin_noise:
         return perlin_color<R>(sc.perlins[m.texture], hit.point);
+    case orc_material_kind_lambertian_kit_texture:
+    case orc_material_kind_emissive_kit_texture:
+        return kit_texture_color<R>(sc, (int)m.texture, hit.u, hit.v, hit.point);
     default:
         return V3<R>(R(m.albedo[0]), R(m.albedo[1]), R(m.albedo[2]));
     }
@@ -959,6 +1038,7 @@ template <class R> bool scatter(const Scene &sc, const OrcMaterial &m, Ray<R> ra
     case orc_material_kind_lambertian_colored:
     case orc_material_kind_lambertian_textured:
     case orc_material_kind_lambertian_perlin_noise:
+    case orc_material_kind_lambertian_kit_texture:
         while (true) {
             V3<R> d = hit.normal + random_unit_vector_3d<R>(rng);
             R len_sq = length_squared(d);
@@ -987,6 +1067,9 @@ template <class R> bool scatter(const Scene &sc, const OrcMaterial &m, Ray<R> ra
     }
     case orc_material_kind_emissive_colored:
         res.emitted = V3<R>(R(m.albedo[0]), R(m.albedo[1]), R(m.albedo[2]));
+        return false;
+    case orc_material_kind_emissive_kit_texture:
+        res.emitted = material_color(sc, m, hit);
         return false;
     case orc_material_kind_isotropic_colored:
         res.scattered = {hit.point, random_unit_vector_3d<R>(rng)};
@@ -1057,7 +1140,8 @@ template <class R> V3<R> ray_color(const Scene &sc, uint32_t background, Ray<R> 
     HitInfo<R> hit;
     if (!scene_hit<R>(ctx, ray, R(kTMin), kInf<R>(), hit)) return background_color<R>(background, ray.direction);
     const OrcMaterial &m = sc.materials[hit.material_offset];
-    if (counters) counters->shades[m.kind < 10 ? m.kind : 0]++;
+    // the texture-backed RayTracingKit kinds count with the kinds they scatter like
+    if (counters) counters->shades[m.kind == orc_material_kind_lambertian_kit_texture ? 1 : (m.kind == orc_material_kind_emissive_kit_texture ? 8 : (m.kind < 10 ? m.kind : 0))]++;
     ScatterResult<R> res;
     bool did = scatter<R>(sc, m, ray, hit, rng, res);
     if (!did) return res.emitted;

@@ -55,6 +55,8 @@ enum {
     orc_material_kind_dielectric,
     orc_material_kind_emissive_colored,
     orc_material_kind_isotropic_colored,
+    orc_material_kind_lambertian_kit_texture,   /* RayTracingKit/Material.swift:17-41 over any Texture */
+    orc_material_kind_emissive_kit_texture,     /* Material.swift:75-93 */
 };
 
 /* One flat record for every material kind (the reference packs nine structs,
@@ -135,6 +137,22 @@ void orc_scene_destroy(OrcScene *);
 
 int orc_add_material(OrcScene *, const OrcMaterial *);                 /* -> material_offset handle */
 int orc_add_texture_rgb8(OrcScene *, int w, int h, const uint8_t *rgb); /* rows top to bottom */
+/* RayTracingKit textures (Texture.swift); same record layouts as include/raytracer_amd.h. */
+typedef struct OrcKitPerlin { float vectors[256][3]; uint8_t perm_x[256], perm_y[256], perm_z[256]; } OrcKitPerlin;
+typedef struct OrcKitTexture {
+    uint32_t kind;                  /* 0 solid, 1 checker, 2 image, 3 noise, 4 marble */
+    float color[3];
+    float scale;
+    int32_t even, odd;
+    int32_t image;
+    int32_t origin_x, origin_y, width, height;
+    uint32_t wrap_x, wrap_y;
+    int32_t perlin;
+} OrcKitTexture;
+int orc_add_kit_perlin(OrcScene *, const OrcKitPerlin *);
+int orc_add_kit_texture(OrcScene *, const OrcKitTexture *);
+/* One texture lookup: Texture.subscript(coordinates, point:). */
+int orc_kit_texture_color(const OrcScene *, int texture, int precision, double u, double v, const double point[3], double out_rgb[3]);
 int orc_add_perlin(OrcScene *, const OrcPerlin *);
 
 int orc_shape_sphere(OrcScene *, const OrcSphere *);     /* -> shape id */

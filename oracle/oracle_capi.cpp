@@ -20,7 +20,7 @@ OrcScene *orc_scene_create(void) { return new OrcScene(); }
 void orc_scene_destroy(OrcScene *s) { delete s; }
 
 int orc_add_material(OrcScene *s, const OrcMaterial *m) {
-    if (m->kind < 1 || m->kind > 9) return fail("material kind out of range");
+    if (m->kind < 1 || m->kind > orc_material_kind_emissive_kit_texture) return fail("material kind out of range");
     s->s.materials.push_back(*m);
     return (int)s->s.materials.size() - 1;
 }
@@ -34,6 +34,25 @@ int orc_add_texture_rgb8(OrcScene *s, int w, int h, const uint8_t *rgb) {
     return (int)s->s.images.size() - 1;
 }
 
+int orc_add_kit_perlin(OrcScene *s, const OrcKitPerlin *p) {
+    s->s.kit_perlins.push_back(*p);
+    return (int)s->s.kit_perlins.size() - 1;
+}
+int orc_add_kit_texture(OrcScene *s, const OrcKitTexture *t) {
+    s->s.kit_textures.push_back(*t);
+    return (int)s->s.kit_textures.size() - 1;
+}
+int orc_kit_texture_color(const OrcScene *s, int texture, int precision, double u, double v, const double point[3], double out_rgb[3]) {
+    if (texture < 0 || texture >= (int)s->s.kit_textures.size()) return fail("bad texture id");
+    if (precision == ORC_F32) {
+        V3<float> c = kit_texture_color<float>(s->s, texture, (float)u, (float)v, V3<float>((float)point[0], (float)point[1], (float)point[2]));
+        out_rgb[0] = c.x; out_rgb[1] = c.y; out_rgb[2] = c.z;
+    } else {
+        V3<double> c = kit_texture_color<double>(s->s, texture, u, v, V3<double>(point[0], point[1], point[2]));
+        out_rgb[0] = c.x; out_rgb[1] = c.y; out_rgb[2] = c.z;
+    }
+    return 0;
+}
 int orc_add_perlin(OrcScene *s, const OrcPerlin *p) {
     s->s.perlins.push_back(*p);
     return (int)s->s.perlins.size() - 1;

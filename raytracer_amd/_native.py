@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("RT_LIB") or os.path.join(HERE, "lib", "libraytracer_a
 # every symbol include/raytracer_amd.h declares
 EXPORTS = [
     "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_abi_version",
-    "rt_scene_create", "rt_scene_destroy", "rt_add_material", "rt_add_texture_rgb8",
+    "rt_scene_create", "rt_scene_destroy", "rt_add_material", "rt_add_texture_rgb8", "rt_add_kit_perlin", "rt_add_kit_texture",
     "rt_shape_sphere", "rt_shape_cylinder", "rt_shape_cuboid", "rt_shape_quad", "rt_shape_csg", "rt_shape_cdv",
     "rt_shape_motion", "rt_shape_bounds", "rt_scene_set_time",
     "rt_add_object", "rt_add_sphere_objects", "rt_scene_commit", "rt_scene_stats", "rt_scene_set_option",
@@ -41,6 +41,8 @@ def _load():
         "rt_scene_destroy": (None, [vp]),
         "rt_add_material": (i32, [vp, vp, C.c_size_t]),
         "rt_add_texture_rgb8": (i32, [vp, i32, i32, vp]),
+        "rt_add_kit_perlin": (i32, [vp, C.POINTER(abi.RtKitPerlin)]),
+        "rt_add_kit_texture": (i32, [vp, C.POINTER(abi.RtKitTexture)]),
         "rt_shape_sphere": (i32, [vp, C.POINTER(abi.RtSphere)]),
         "rt_shape_cylinder": (i32, [vp, C.POINTER(abi.RtCylinder)]),
         "rt_shape_cuboid": (i32, [vp, C.POINTER(abi.RtCuboid)]),

@@ -121,6 +121,25 @@ class RtEvent(C.Structure):
                 ("material_offset", C.c_uint32), ("is_exit", C.c_int32), ("pad", C.c_int32)]
 
 
+class RtKitPerlin(C.Structure):
+    _fields_ = [("vectors", C.c_float * 3 * 256), ("perm_x", C.c_uint8 * 256), ("perm_y", C.c_uint8 * 256),
+                ("perm_z", C.c_uint8 * 256)]
+
+
+class RtKitTexture(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("color", C.c_float * 3), ("scale", C.c_float), ("even", C.c_int32), ("odd", C.c_int32),
+                ("image", C.c_int32), ("origin_x", C.c_int32), ("origin_y", C.c_int32), ("width", C.c_int32),
+                ("height", C.c_int32), ("wrap_x", C.c_uint32), ("wrap_y", C.c_uint32), ("perlin", C.c_int32)]
+
+
+class RtKitTexturedMaterial(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("texture", C.c_uint32)]
+
+
+RT_KIT_TEXTURE_SOLID, RT_KIT_TEXTURE_CHECKER, RT_KIT_TEXTURE_IMAGE, RT_KIT_TEXTURE_NOISE, RT_KIT_TEXTURE_MARBLE = range(5)
+material_kind_lambertian_kit_texture, material_kind_emissive_kit_texture = 10, 11
+
+
 class RtMotion(C.Structure):
     _fields_ = [("rotation", C.c_float * 4), ("translation", C.c_float * 3)]
 

@@ -822,7 +822,7 @@ RT_DEV Material unpack_material(float4 a, float4 b) {
     m.albedo = mk3(b.x, b.y, b.z);
     return m;
 }
-RT_DEV bool material_wants_uv(uint32_t kind) { return kind == 2u || kind == 5u; }
+RT_DEV bool material_wants_uv(uint32_t kind) { return kind == 2u || kind == 5u || kind >= 10u; }
 
 // MaterialsImpl.h:53-58: normalised coordinates, nearest texel, clamp to edge; v = 0 is the
 // bottom row (the loader's bottom-left origin), rows are stored top to bottom.
@@ -878,12 +878,91 @@ RT_DEV f3 perlin_color(const RtDevScene &s, uint32_t id, f3 point) {
     return madd(c1 - c0, t, c0);
 }
 
+// ---- RayTracingKit textures
+// PerlinNoise subscript, Texture.swift:184-209: the lattice cell comes from Int(x), which
+// truncates towards zero, while the fraction comes from floor (kept as is).
+RT_DEV float kit_perlin_noise(const RtDevKitPerlin &n, f3 p) {
+    float u = p.x - floorf(p.x), v = p.y - floorf(p.y), w = p.z - floorf(p.z);
+    float uu = u * u * (3.0f - 2.0f * u), vv = v * v * (3.0f - 2.0f * v), ww = w * w * (3.0f - 2.0f * w);
+    int i = (int)p.x, j = (int)p.y, k = (int)p.z;
+    float result = 0.0f;
+#pragma unroll
+    for (int di = 0; di < 2; di++)
+#pragma unroll
+        for (int dj = 0; dj < 2; dj++)
+#pragma unroll
+            for (int dk = 0; dk < 2; dk++) {
+                uint32_t index = n.perm[0][(i + di) & 255] ^ n.perm[1][(j + dj) & 255] ^ n.perm[2][(k + dk) & 255];
+                float weight = (di == 0 ? 1.0f - uu : uu) * (dj == 0 ? 1.0f - vv : vv) * (dk == 0 ? 1.0f - ww : ww);
+                result = fmaf(weight, dot(ld3(n.vectors[index]), mk3(u - (float)di, v - (float)dj, w - (float)dk)), result);
+            }
+    return result;
+}
+// Texture.swift:211-223
+RT_DEV float kit_turbulence(const RtDevKitPerlin &n, f3 p, int octaves) {
+    float accum = 0.0f, weight = 1.0f;
+    for (int o = 0; o < octaves; o++) {
+        accum = fmaf(weight, kit_perlin_noise(n, p), accum);
+        weight *= 0.5f;
+        p = p * 2.0f;
+    }
+    return accum;
+}
+// ImageTexture.clip, Texture.swift:103-120 (Swift's % truncates, like C's)
+RT_DEV int kit_clip(int index, int size, bool wrap) {
+    if (index < 0) return wrap ? size + (index % size) : 0;
+    if (index >= size) return wrap ? index % size : size - 1;
+    return index;
+}
+RT_DEV f3 kit_texel(const RtDevScene &s, const RtDevKitTexture &t, const RtDevTexture &img, int i, int j) {
+    int row = t.origin_y + kit_clip(i, t.height, t.wrap_y != 0u) * t.step_y;
+    int col = t.origin_x + kit_clip(j, t.width, t.wrap_x != 0u) * t.step_x;
+    // the reference asserts on indices outside the image (Image.swift:65-68); clamp instead of faulting
+    row = min(max(row, 0), (int)img.height - 1);
+    col = min(max(col, 0), (int)img.width - 1);
+    uint32_t px = s.texels[img.offset + (uint32_t)row * img.width + (uint32_t)col];
+    return mk3((float)(px & 255u), (float)((px >> 8) & 255u), (float)((px >> 16) & 255u)) * (1.0f / 255.0f);
+}
+// Texture subscripts, Texture.swift:24,44-50,80-93,145-148,160-163.  A checker only picks
+// one of its two textures, so nesting is a loop, not a recursion.
+RT_DEV f3 kit_texture_color(const RtDevScene &s, uint32_t id, float u, float v, f3 point) {
+    RtDevKitTexture t = s.kit_textures[id];
+    for (int hop = 0; hop < 8 && t.kind == 1u; hop++) {
+        int xi = (int)floorf(t.scale * point.x), yi = (int)floorf(t.scale * point.y), zi = (int)floorf(t.scale * point.z);
+        bool even = ((xi + yi + zi) % 2) == 0;
+        t = s.kit_textures[even ? t.even : t.odd];
+    }
+    switch (t.kind) {
+    case 2: {
+        RtDevTexture img = s.textures[t.image];
+        float fi = fmaf(v, (float)t.height, -0.5f), fj = fmaf(u, (float)t.width, -0.5f);
+        float i1f = floorf(fi), j1f = floorf(fj);
+        int i1 = (int)i1f, j1 = (int)j1f;
+        float a = fi - i1f, b = fj - j1f;
+        f3 c1 = kit_texel(s, t, img, i1, j1) * (1.0f - b) + kit_texel(s, t, img, i1, j1 + 1) * b;
+        f3 c2 = kit_texel(s, t, img, i1 + 1, j1) * (1.0f - b) + kit_texel(s, t, img, i1 + 1, j1 + 1) * b;
+        return c1 * (1.0f - a) + c2 * a;
+    }
+    case 3: {
+        float grey = fabsf(kit_turbulence(s.kit_perlin[t.perlin], point * t.scale, 7));
+        return mk3(grey, grey, grey);
+    }
+    case 4: {
+        float grey = (1.0f + sinf(fmaf(t.scale, point.z, 10.0f * kit_turbulence(s.kit_perlin[t.perlin], point, 7)))) * 0.5f;
+        return mk3(grey, grey, grey);
+    }
+    default:
+        return mk3(t.color[0], t.color[1], t.color[2]);
+    }
+}
+
 // TEXTURES = false compiles the image / Perlin paths out (scenes without such materials).
 template <bool TEXTURES>
 RT_DEV f3 material_color(const RtDevScene &s, const Material &m, const HitRecord &h) {
     if (TEXTURES) {
         if (m.kind == 2u || m.kind == 5u) return sample_image(s, m.texture, h.u, h.v);
         if (m.kind == 3u || m.kind == 6u) return perlin_color(s, m.texture, h.point);
+        if (m.kind >= 10u) return kit_texture_color(s, m.texture, h.u, h.v, h.point);
     }
     return m.albedo;
 }
@@ -907,9 +986,9 @@ RT_DEV bool scatter(const RtDevScene &s, const Material &m, f3 d, const HitRecor
     // lambertian, metal and isotropic all start by drawing one unit vector: drawn once
     // here, so that a wave holding a mix of them runs the rejection loop once
     f3 rv = mk3(0, 0, 0);
-    if (m.kind != 7u && m.kind != 8u) rv = random_unit_vector_3d(g);
+    if (m.kind != 7u && m.kind != 8u && m.kind != 11u) rv = random_unit_vector_3d(g);
     switch (m.kind) {
-    case 1: case 2: case 3: {      // lambertian
+    case 1: case 2: case 3: case 10: {      // lambertian
         while (true) {
             f3 v = h.normal + rv;
             float len_sq = dot(v, v);
@@ -941,6 +1020,9 @@ RT_DEV bool scatter(const RtDevScene &s, const Material &m, f3 d, const HitRecor
     }
     case 8:                        // emissive
         emitted = m.albedo;
+        return false;
+    case 11:                       // Emissive over a texture, RayTracingKit/Material.swift:75-93
+        emitted = material_color<TEXTURES>(s, m, h);
         return false;
     default:                       // isotropic
         new_d = rv;

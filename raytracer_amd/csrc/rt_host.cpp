@@ -74,6 +74,8 @@ struct RtScene {
     std::vector<uint32_t> material_kinds;
     std::vector<HostTexture> textures;
     std::vector<RtDevPerlin> perlin;
+    std::vector<RtDevKitTexture> kit_textures;
+    std::vector<RtDevKitPerlin> kit_perlin;
     // bulk spheres (kept as arrays: a million HostShape records would be wasteful)
     std::vector<float> bulk_spheres;       // cx, cy, cz, r
     std::vector<uint32_t> bulk_mats;
@@ -576,6 +578,12 @@ int rt_add_material(RtScene *sc, const void *record, size_t size) {
         rec[2] = m->fuzz;
         break;
     }
+    case rt_material_kind_lambertian_kit_texture:
+    case rt_material_kind_emissive_kit_texture:
+        if (want(sizeof(RtKitTexturedMaterial)) < 0) return RT_ERR_INVALID;
+        tex = ((const RtKitTexturedMaterial *)record)->texture;
+        if (tex >= sc->kit_textures.size()) return fail(RT_ERR_INVALID, "texture does not name a texture added with rt_add_kit_texture");
+        break;
     case rt_material_kind_dielectric:
         if (want(sizeof(RtDielectricMaterial)) < 0) return RT_ERR_INVALID;
         rec[3] = ((const RtDielectricMaterial *)record)->refraction_index;
@@ -588,6 +596,64 @@ int rt_add_material(RtScene *sc, const void *record, size_t size) {
     sc->materials.insert(sc->materials.end(), rec, rec + 8);
     sc->material_kinds.push_back(kind);
     return (int)sc->material_kinds.size() - 1;
+}
+
+int rt_add_kit_perlin(RtScene *sc, const RtKitPerlin *p) {
+    if (!sc || !p) return fail(RT_ERR_INVALID, "null argument");
+    if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
+    RtDevKitPerlin d;
+    memcpy(d.vectors, p->vectors, sizeof(d.vectors));
+    memcpy(d.perm[0], p->perm_x, 256);
+    memcpy(d.perm[1], p->perm_y, 256);
+    memcpy(d.perm[2], p->perm_z, 256);
+    sc->kit_perlin.push_back(d);
+    return (int)sc->kit_perlin.size() - 1;
+}
+
+int rt_add_kit_texture(RtScene *sc, const RtKitTexture *t) {
+    if (!sc || !t) return fail(RT_ERR_INVALID, "null argument");
+    if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
+    RtDevKitTexture d;
+    memset(&d, 0, sizeof(d));
+    d.kind = t->kind;
+    const int n = (int)sc->kit_textures.size();
+    switch (t->kind) {
+    case RT_KIT_TEXTURE_SOLID:
+        memcpy(d.color, t->color, 12);
+        break;
+    case RT_KIT_TEXTURE_CHECKER:
+        // children come first, so chains of checkers end
+        if (t->even < 0 || t->even >= n || t->odd < 0 || t->odd >= n) return fail(RT_ERR_INVALID, "checker children must be textures added before it");
+        if (!(t->scale != 0.f)) return fail(RT_ERR_INVALID, "checker scale must not be zero");
+        d.scale = 1.f / t->scale;        // Texture.swift:33
+        d.even = t->even; d.odd = t->odd;
+        break;
+    case RT_KIT_TEXTURE_IMAGE: {
+        if (t->image < 0 || t->image >= (int)sc->textures.size()) return fail(RT_ERR_INVALID, "image does not name a texture added with rt_add_texture_rgb8");
+        if (t->width == 0 || t->height == 0) return fail(RT_ERR_INVALID, "image window must not be empty");
+        const HostTexture &img = sc->textures[(size_t)t->image];
+        d.image = (uint32_t)t->image;
+        d.origin_x = t->origin_x; d.origin_y = t->origin_y;
+        d.width = std::abs(t->width); d.height = std::abs(t->height);      // Texture.swift:72-75
+        d.step_x = t->width < 0 ? -1 : 1; d.step_y = t->height < 0 ? -1 : 1;
+        d.wrap_x = t->wrap_x ? 1u : 0u; d.wrap_y = t->wrap_y ? 1u : 0u;
+        long x_end = (long)d.origin_x + (long)(d.width - 1) * d.step_x, y_end = (long)d.origin_y + (long)(d.height - 1) * d.step_y;
+        if (d.origin_x < 0 || d.origin_x >= img.w || x_end < 0 || x_end >= img.w || d.origin_y < 0 || d.origin_y >= img.h ||
+            y_end < 0 || y_end >= img.h)
+            return fail(RT_ERR_INVALID, "image window reaches outside the image");   // the reference asserts, Image.swift:65-68
+        break;
+    }
+    case RT_KIT_TEXTURE_NOISE:
+    case RT_KIT_TEXTURE_MARBLE:
+        if (t->perlin < 0 || t->perlin >= (int)sc->kit_perlin.size()) return fail(RT_ERR_INVALID, "perlin does not name tables added with rt_add_kit_perlin");
+        d.perlin = (uint32_t)t->perlin;
+        d.scale = t->scale;
+        break;
+    default:
+        return fail(RT_ERR_INVALID, "unknown texture kind");
+    }
+    sc->kit_textures.push_back(d);
+    return n;
 }
 
 int rt_add_texture_rgb8(RtScene *sc, int width, int height, const uint8_t *rgb) {
@@ -904,7 +970,7 @@ int rt_scene_commit(RtScene *sc) {
             it.c[a] = std::isfinite(c) ? c : 0.f;
         }
     for (uint32_t k : sc->material_kinds)
-        if (k == 2 || k == 3 || k == 5 || k == 6) feat |= RT_FEAT_TEXTURE;
+        if (k == 2 || k == 3 || k == 5 || k == 6 || k >= 10) feat |= RT_FEAT_TEXTURE;
 
     uint32_t root = RT_REF_NONE;
     if (bld.items.size() == 1) {
@@ -976,6 +1042,8 @@ int rt_scene_commit(RtScene *sc) {
     if ((rc = upload(sc, tex_desc, &d.textures)) < 0) return rc;
     if ((rc = upload(sc, texels, &d.texels)) < 0) return rc;
     if ((rc = upload(sc, sc->perlin, &d.perlin)) < 0) return rc;
+    if ((rc = upload(sc, sc->kit_textures, &d.kit_textures)) < 0) return rc;
+    if ((rc = upload(sc, sc->kit_perlin, &d.kit_perlin)) < 0) return rc;
     d.root = root;
     d.n_nodes = (uint32_t)(bld.nodes.size() / 16);
     sc->feat = feat;

@@ -69,6 +69,23 @@ struct RtDevTexture {
     uint32_t width, height, pad;
 };
 
+// RayTracingKit textures (Texture.swift).  One record per texture; checker records name two others.
+struct RtDevKitTexture {
+    uint32_t kind;                      // RtKitTextureKind
+    float color[3];
+    float scale;                        // checker: 1 / scale
+    int32_t even, odd;
+    uint32_t image;                     // index into `textures`
+    int32_t origin_x, origin_y, width, height;   // width, height > 0
+    int32_t step_x, step_y;             // +1 / -1
+    uint32_t wrap_x, wrap_y;
+    uint32_t perlin;
+};
+struct RtDevKitPerlin {
+    float vectors[256][3];
+    uint8_t perm[3][256];
+};
+
 struct RtDevPerlin {
     float colors[2][3];
     float frequency;
@@ -100,6 +117,8 @@ struct RtDevScene {
     const RtDevTexture *textures;
     const uint32_t *texels;
     const RtDevPerlin *perlin;
+    const RtDevKitTexture *kit_textures;
+    const RtDevKitPerlin *kit_perlin;
     uint32_t root;                 // child reference of the root (RT_REF_NONE for an empty scene)
     uint32_t n_nodes;
 };

@@ -65,6 +65,12 @@ class NativeScene:
         buf = np.ascontiguousarray(pixels, dtype=np.uint8)
         return check(lib.rt_add_texture_rgb8(self.h, w, h, buf.ctypes.data_as(C.c_void_p)))
 
+    def add_kit_perlin(self, rec):
+        return check(lib.rt_add_kit_perlin(self.h, C.byref(rec)))
+
+    def add_kit_texture(self, rec):
+        return check(lib.rt_add_kit_texture(self.h, C.byref(rec)))
+
     def shape_sphere(self, rec):
         return check(lib.rt_shape_sphere(self.h, C.byref(rec)))
 

@@ -192,6 +192,114 @@ class PerlinNoiseTexture:
         return t
 
 
+# ---------------------------------------------------------------------------- RayTracingKit textures
+class KitTexture:
+    """RayTracingKit/Texture.swift:9-11.  `encode` registers the texture (children first)
+    with the sink and returns its handle."""
+
+    def encode(self, encoder):
+        key = id(self)
+        if key not in encoder._kit:      # the object is kept with its handle: ids of dead objects get reused
+            encoder._kit[key] = (encoder.sink.add_kit_texture(self.record(encoder)), self)
+        return encoder._kit[key][0]
+
+
+class SolidColor(KitTexture):
+    """Texture.swift:13-25."""
+
+    def __init__(self, albedo):
+        self.albedo = vec3(albedo)
+
+    def record(self, encoder):
+        t = abi.RtKitTexture()
+        t.kind = abi.RT_KIT_TEXTURE_SOLID
+        t.color = _f3(self.albedo)
+        return t
+
+
+class CheckerTexture(KitTexture):
+    """Texture.swift:27-51: colours or textures for the even and odd cells."""
+
+    def __init__(self, scale, even, odd):
+        self.scale = float(scale)
+        self.even = even if isinstance(even, KitTexture) else SolidColor(even)
+        self.odd = odd if isinstance(odd, KitTexture) else SolidColor(odd)
+
+    def record(self, encoder):
+        t = abi.RtKitTexture()
+        t.kind = abi.RT_KIT_TEXTURE_CHECKER
+        t.scale = self.scale
+        t.even = self.even.encode(encoder)
+        t.odd = self.odd.encode(encoder)
+        return t
+
+
+class BilinearImageTexture(KitTexture):
+    """ImageTexture of the Kit, Texture.swift:53-120: a window of an image (negative width /
+    height run towards smaller indices), bilinear, wrapped or clamped.  `image` is an
+    ImageTexture (name + RGB8 rows, top to bottom)."""
+
+    def __init__(self, image, origin_x=None, origin_y=None, width=None, height=None, wrap_x=True, wrap_y=True):
+        h, w, _ = image.pixels.shape
+        self.image = image
+        if origin_x is None:          # init(image:), Texture.swift:64-66
+            origin_x, origin_y, width, height = 0, h - 1, w, -h
+        self.origin_x, self.origin_y, self.width, self.height = int(origin_x), int(origin_y), int(width), int(height)
+        self.wrap_x, self.wrap_y = bool(wrap_x), bool(wrap_y)
+
+    def record(self, encoder):
+        t = abi.RtKitTexture()
+        t.kind = abi.RT_KIT_TEXTURE_IMAGE
+        t.image = encoder.load_texture(self.image)
+        t.origin_x, t.origin_y, t.width, t.height = self.origin_x, self.origin_y, self.width, self.height
+        t.wrap_x, t.wrap_y = int(self.wrap_x), int(self.wrap_y)
+        return t
+
+
+class KitPerlinNoise:
+    """PerlinNoise, Texture.swift:166-182: 256 vectors with components in [-1, 1] and three
+    shuffled byte tables (the caller's seeded generator stands in for the system one)."""
+
+    def __init__(self, rng):
+        self.vectors = np.array([[rng.uniform(-1, 1) for _ in range(3)] for _ in range(256)], dtype=np.float32)
+        self.perms = []
+        for _ in range(3):
+            p = list(range(256))
+            rng.shuffle(p)
+            self.perms.append(np.array(p, dtype=np.uint8))
+
+    def encode(self, encoder):
+        key = id(self)
+        if key not in encoder._kit:
+            rec = abi.RtKitPerlin()
+            C.memmove(rec.vectors, self.vectors.tobytes(), 256 * 12)
+            for name, p in zip(("perm_x", "perm_y", "perm_z"), self.perms):
+                C.memmove(getattr(rec, name), p.tobytes(), 256)
+            encoder._kit[key] = (encoder.sink.add_kit_perlin(rec), self)
+        return encoder._kit[key][0]
+
+
+class NoiseTexture(KitTexture):
+    """Texture.swift:136-149."""
+    KIND = abi.RT_KIT_TEXTURE_NOISE
+
+    def __init__(self, noise, scale):
+        self.noise = noise
+        self.scale = float(scale)
+
+    def record(self, encoder):
+        t = abi.RtKitTexture()
+        t.kind = self.KIND
+        t.scale = self.scale
+        t.perlin = self.noise.encode(encoder)
+        return t
+
+
+class Marble(NoiseTexture):
+    """Texture.swift:151-164."""
+    KIND = abi.RT_KIT_TEXTURE_MARBLE
+
+
 # ---------------------------------------------------------------------------- materials
 class Material:
     """Material.swift:8-19."""
@@ -215,6 +323,26 @@ class TexturedLambertian(Material):
     def as_impl(self, encoder):
         tid = encoder.load_texture(self.albedo)
         return abi.RtTexturedLambertianMaterial(abi.material_kind_lambertian_textured, abi.RtImageTexture(tid))
+
+
+class KitLambertian(Material):
+    """Lambertian(texture:), RayTracingKit/Material.swift:17-41."""
+
+    def __init__(self, texture):
+        self.texture = texture
+
+    def as_impl(self, encoder):
+        return abi.RtKitTexturedMaterial(abi.material_kind_lambertian_kit_texture, self.texture.encode(encoder))
+
+
+class KitEmissive(Material):
+    """Emissive(texture:), RayTracingKit/Material.swift:75-93."""
+
+    def __init__(self, texture):
+        self.texture = texture
+
+    def as_impl(self, encoder):
+        return abi.RtKitTexturedMaterial(abi.material_kind_emissive_kit_texture, self.texture.encode(encoder))
 
 
 class PerlinNoiseLambertian(Material):
@@ -300,6 +428,7 @@ class SceneEncoder:
         self.dedup = dedup
         self._materials = {}
         self._textures = {}
+        self._kit = {}           # RayTracingKit textures and noise tables already registered
 
     def load_texture(self, tex):
         if tex.name not in self._textures:

@@ -13,7 +13,8 @@ from . import abi
 from .scene import (CameraConfig, ColoredEmissive, ColoredIsotropic, ColoredLambertian, ColoredMetal,
                     ConstantDensityVolume, Cuboid, Cylinder, Dielectric, ImageTexture, Intersection,
                     PerlinNoiseLambertian, PerlinNoiseTexture, Quad, Scene, Sphere, Subtract,
-                    TexturedLambertian, Transform, Union, WyRand, u64_to_unit, wyrand_block, MotionBlur)
+                    TexturedLambertian, Transform, Union, WyRand, u64_to_unit, wyrand_block, MotionBlur,
+                    BilinearImageTexture, CheckerTexture, KitEmissive, KitLambertian, KitPerlinNoise, Marble, NoiseTexture)
 from .simd import Quat, normalize, vec3
 
 T = Transform
@@ -222,6 +223,58 @@ def bouncing_spheres(seed=1):
     return Scene(base.camera, objs)
 
 
+def kit_world1(seed=3):
+    """makeWorld1 of the command-line renderer (RayTracing/main.swift:11-104) with the Kit's
+    own textures: an earth-like image on a tilted sphere, three barrels whose caps and
+    side are windows of one 512x512 image (bilinear, the side window mirrored in v), a
+    glass lens as an intersection of two spheres, a ceiling light, a mirror ball and two
+    coloured quads.  Procedural images stand in for the bundled JPEGs."""
+    earth = ImageTexture.procedural("kit-earthmap", 512, 256, seed)
+    barrel = ImageTexture.procedural("kit-barrel", 512, 512, seed + 1)
+    glass = Dielectric(1.5)
+    lens = Intersection(Sphere((0, 1, -9.915), 10.0, glass), Sphere((0, 1, 9.915), 10.0, glass))
+    top = KitLambertian(BilinearImageTexture(barrel, 128, 320, 192, 192))
+    bottom = KitLambertian(BilinearImageTexture(barrel, 320, 320, 192, 192))
+    side = KitLambertian(BilinearImageTexture(barrel, 0, 320, 512, -320))
+    T = Transform
+    barrels = [Cylinder(tr, 0.5, 2.0, bottom=bottom, top=top, side=side) for tr in (
+        T.translate(0, 0, 3),
+        T.translate(-1.2, 0, 2.7) * T.rotation_deg(115, "y"),
+        T.translate(-1.7, 0.5, 3.5) * T.rotation_deg(-30, "y") * T.rotation_deg(-90, "z") * T.rotation_deg(90, "y"))]
+    objs = [
+        Sphere((0, -1000, 0), 1000, ColoredLambertian((0.5, 0.5, 0.5))),
+        lens,
+        Sphere(radius=1.0, material=KitLambertian(BilinearImageTexture(earth)),
+               transform=T.translate(-4, 1, 0) * T.rotation_deg(23, "z") * T.rotation_deg(190, "y")),
+        Quad((-5, 10, 5), (10, 0, 0), (0, 0, -10), ColoredEmissive((4, 4, 4))),
+        Sphere((4, 1, 0), 1.0, ColoredMetal((0.7, 0.6, 0.5), 0.0)),
+    ] + barrels + [
+        Quad((-1, 0, -2), (0, 0.8, 0), (5.5, 0, 0), ColoredLambertian((0.7, 0.8, 0.0))),
+        Quad((-1, 0, -2), (0, 0, 0.8), (5.5, 0, 0), ColoredLambertian((0.0, 1.0, 0.8))),
+    ]
+    cam = CameraConfig(vertical_fov=20, look_from=(-10, 6, 8), look_at=(0, 0, 0), defocus_angle=0.6,
+                       focus_distance=10, background=abi.background_lighting_none)
+    return Scene(cam, objs)
+
+
+def kit_world2(seed=4):
+    """makeWorld2 (RayTracing/main.swift:106-125): a noise-textured ground and a marble
+    sphere, plus a checkered block lit by a textured light so that every Kit texture kind
+    is on screen."""
+    rng = WyRand(seed)
+    noise_tex = NoiseTexture(KitPerlinNoise(rng), 1.0)
+    marble = Marble(KitPerlinNoise(rng), 1.0)
+    checker = CheckerTexture(0.32, (0.2, 0.3, 0.1), CheckerTexture(0.08, (0.9, 0.9, 0.9), marble))
+    objs = [
+        Sphere((0, -1000, 0), 1000, KitLambertian(noise_tex)),
+        Sphere((0, 2, 0), 2, KitLambertian(marble)),
+        Cuboid(Transform.translate(2.5, 0, 1.5), (1.2, 1.2, 1.2), KitLambertian(checker)),
+        Quad((-2, 6, -2), (4, 0, 0), (0, 0, 4), KitEmissive(CheckerTexture(1.0, (6, 6, 6), (6, 3, 1)))),
+    ]
+    cam = CameraConfig(vertical_fov=20, look_from=(13, 2, 3), look_at=(0, 0, 0), background=abi.background_lighting_sky)
+    return Scene(cam, objs)
+
+
 def cornell_smoke():
     """Cornell box with two smoke-filled boxes: six quads spanning 555^3, an emissive
     ceiling quad, two rotated cuboids wrapped in constant-density volumes."""
@@ -323,6 +376,8 @@ WORKLOADS = {
     "cfg4_csg_textured_1080p": (csg_textured, 1920, 1080, 2048, 50, 7),
     "cfg5_sphere_cloud_4k": (SphereCloud, 3840, 2160, 8192, 50, 42),
     "f2_bouncing_spheres_1080p": (bouncing_spheres, 1920, 1080, 256, 50, 1),
+    "f3_kit_world1_1080p": (kit_world1, 1920, 1080, 100, 50, 3),
+    "f3_kit_world2_1080p": (kit_world2, 1920, 1080, 100, 50, 4),
 }
 
 

@@ -70,7 +70,7 @@ def lib():
         L.orc_last_error.restype = C.c_char_p
         for name in ("orc_scene_destroy", "orc_add_material", "orc_add_texture_rgb8", "orc_add_perlin",
                      "orc_shape_sphere", "orc_shape_cylinder", "orc_shape_cuboid", "orc_shape_quad",
-                     "orc_shape_csg", "orc_shape_cdv", "orc_shape_motion", "orc_shape_bounds", "orc_add_object", "orc_commit", "orc_enumerate",
+                     "orc_add_kit_perlin", "orc_add_kit_texture", "orc_kit_texture_color", "orc_shape_csg", "orc_shape_cdv", "orc_shape_motion", "orc_shape_bounds", "orc_add_object", "orc_commit", "orc_enumerate",
                      "orc_first_hit", "orc_render"):
             getattr(L, name).argtypes = None
         _lib = L
@@ -114,6 +114,8 @@ class OracleScene:
             m.fuzz = rec.fuzz
         if k == abi.material_kind_dielectric:
             m.refraction_index = rec.refraction_index
+        if k in (abi.material_kind_lambertian_kit_texture, abi.material_kind_emissive_kit_texture):
+            m.texture = rec.texture
         return _check(self.L.orc_add_material(self.h, C.byref(m)))
 
     def add_dummy_materials(self, n):
@@ -123,6 +125,18 @@ class OracleScene:
     def add_texture_rgb8(self, w, h, pixels):
         buf = np.ascontiguousarray(pixels, dtype=np.uint8)
         return _check(self.L.orc_add_texture_rgb8(self.h, C.c_int(w), C.c_int(h), buf.ctypes.data_as(C.c_void_p)))
+
+    def add_kit_perlin(self, rec):
+        return _check(self.L.orc_add_kit_perlin(self.h, C.byref(rec)))      # same layout as OrcKitPerlin
+
+    def add_kit_texture(self, rec):
+        return _check(self.L.orc_add_kit_texture(self.h, C.byref(rec)))     # same layout as OrcKitTexture
+
+    def kit_texture_color(self, texture, u, v, point, precision=None):
+        out = (C.c_double * 3)()
+        _check(self.L.orc_kit_texture_color(self.h, C.c_int(texture), C.c_int(ORC_F64 if precision is None else precision),
+                                            C.c_double(u), C.c_double(v), (C.c_double * 3)(*[float(x) for x in point]), out))
+        return np.array(out[:])
 
     def shape_sphere(self, rec):
         return _check(self.L.orc_shape_sphere(self.h, C.byref(rec)))
