@@ -661,6 +661,33 @@ class ConstantDensityVolume(Renderable):
         return encoder.sink.shape_cdv(self.base.as_impl(encoder), self.density)
 
 
+def Transformed(transform, base):
+    """Transformed of the Kit (RayTracingKit/Hittable.swift:563-602) for a rigid transform
+    that does not change with time: the transform is folded into the shape's own records
+    (a rotated sphere keeps its texture orientation, a quad moves its vectors, a CSG shape
+    or a volume moves its parts), so nothing new reaches the device."""
+    if isinstance(base, Sphere):
+        return Sphere(radius=base.radius, material=base.material, transform=transform * base.transform)
+    if isinstance(base, Cylinder):
+        return Cylinder(transform * base.transform, base.radius, base.height, bottom=base.bottom, top=base.top, side=base.side)
+    if isinstance(base, Cuboid):
+        return Cuboid(transform * base.transform, base.size, materials=base.materials)
+    if isinstance(base, Quad):
+        return Quad(base.origin, base.u, base.v, base.material, transform=transform)
+    if isinstance(base, Subtract):
+        return Subtract(Transformed(transform, base.lhs), Transformed(transform, base.rhs))
+    if isinstance(base, Union):
+        return Union(*[Transformed(transform, it) for it in base.items])
+    if isinstance(base, Intersection):
+        return Intersection(*[Transformed(transform, it) for it in base.items])
+    if isinstance(base, ConstantDensityVolume):
+        return ConstantDensityVolume(Transformed(transform, base.base), base.density)
+    if isinstance(base, MotionBlur):
+        # the motion happens in the outer frame: T (M^t x) = (T M T^-1)^t (T x)
+        return MotionBlur(transform * base.transform * transform.inverse, Transformed(transform, base.base))
+    raise TypeError("cannot transform %r" % (base,))
+
+
 class MotionBlur(Renderable):
     """RayTracingKit/Hittable.swift:528-555: `base` seen through transform.pow(time) for the
     sample's time in [0, 1).  The quaternion is kept with w >= 0 like the Kit's

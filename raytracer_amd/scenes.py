@@ -14,7 +14,7 @@ from .scene import (CameraConfig, ColoredEmissive, ColoredIsotropic, ColoredLamb
                     ConstantDensityVolume, Cuboid, Cylinder, Dielectric, ImageTexture, Intersection,
                     PerlinNoiseLambertian, PerlinNoiseTexture, Quad, Scene, Sphere, Subtract,
                     TexturedLambertian, Transform, Union, WyRand, u64_to_unit, wyrand_block, MotionBlur,
-                    BilinearImageTexture, CheckerTexture, KitEmissive, KitLambertian, KitPerlinNoise, Marble, NoiseTexture)
+                    BilinearImageTexture, CheckerTexture, KitEmissive, KitLambertian, KitPerlinNoise, Marble, NoiseTexture, Transformed)
 from .simd import Quat, normalize, vec3
 
 T = Transform
@@ -232,7 +232,8 @@ def kit_world1(seed=3):
     earth = ImageTexture.procedural("kit-earthmap", 512, 256, seed)
     barrel = ImageTexture.procedural("kit-barrel", 512, 512, seed + 1)
     glass = Dielectric(1.5)
-    lens = Intersection(Sphere((0, 1, -9.915), 10.0, glass), Sphere((0, 1, 9.915), 10.0, glass))
+    lens = Transformed(Transform.translate(-0.5, 0, 0) * Transform.rotation_deg(-45, "y"),
+                       Intersection(Sphere((0, 1, -9.915), 10.0, glass), Sphere((0, 1, 9.915), 10.0, glass)))
     top = KitLambertian(BilinearImageTexture(barrel, 128, 320, 192, 192))
     bottom = KitLambertian(BilinearImageTexture(barrel, 320, 320, 192, 192))
     side = KitLambertian(BilinearImageTexture(barrel, 0, 320, 512, -320))

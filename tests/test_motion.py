@@ -71,6 +71,32 @@ def test_reference_transform_inverse():
     assert np.sum((both.inverse.act(both.act(p)) - p) ** 2) < 1e-10
 
 
+def test_static_transformed_equals_moving_at_the_end_of_the_motion():
+    """Transformed (Hittable.swift:563-602) folded into the records gives the hits MotionBlur
+    gives at time 1, where transform.pow(1) is the transform itself."""
+    from raytracer_amd.scene import Transformed
+    m = [ColoredLambertian((0.1 * i, 0.5, 0.5)) for i in range(1, 7)]
+    tr = T(Quat.from_angle_axis(0.9, (0.6, 0.0, 0.8)), (1.5, -0.5, 0.25))
+    bases = [Sphere(radius=0.7, material=m[0], transform=T.translate(0.2, 0.1, 0) * T.rotation_deg(40, "x")),
+             Cuboid(T.translate(-0.5, -0.4, -0.3), (1.0, 0.8, 0.6), m[1]),
+             Cylinder(T.translate(1, -1, 0), 0.4, 2.0, bottom=m[2], top=m[3], side=m[4]),
+             Subtract(Cuboid(T.translate(-1, -1, -1), (2, 2, 2), m[3]), Sphere((0, 0, 0), 1.25, m[5]))]
+    rays = random_rays(150, 5, radius=7.0, aim_radius=2.5)
+    for base in bases:
+        orc = ob.OracleScene()
+        enc = SceneEncoder(orc)
+        moving = MotionBlur(tr, base).as_impl(enc)
+        still = Transformed(tr, base).as_impl(enc)
+        orc.set_time(1.0)
+        for r in rays:
+            a = orc.enumerate(moving, r[:3], r[3:], precision=ob.ORC_F64)
+            b = orc.enumerate(still, r[:3], r[3:], precision=ob.ORC_F64)
+            assert len(a) == len(b), type(base)
+            for x, y in zip(a, b):
+                assert abs(x.t - y.t) < 2e-5 and np.allclose(x.normal, y.normal, atol=2e-5)
+                assert np.allclose(x.uv, y.uv, atol=2e-4) and x.material_offset == y.material_offset
+
+
 # ---------------------------------------------------------------- oracle and host, no GPU
 def moving_shapes():
     m = [ColoredLambertian((0.1 * i, 0.5, 0.5)) for i in range(1, 7)]
