@@ -81,13 +81,17 @@ RT_DEV Pcg sample_stream(uint64_t rng_seed, uint32_t sample, uint32_t x, uint32_
     return pcg_seed((uint64_t)(uint32_t)(x * 5569u + lo), (uint64_t)(uint32_t)(y * 2707u + hi));
 }
 
+// rnd(g) * 2 - 1 in one rounding: the scaling by 2^-24 and the doubling are exact, so this is
+// the same float as the two-step form.
+RT_DEV float rnd_signed(Pcg &g) { return fmaf((float)(pcg_next(g) >> 8), 1.0f / 8388608.0f, -1.0f); }
+
 #define RT_MIN_LEN_SQ 1e-24f   // RNG.h:13
 
 // RNG.h:59-68: rejection from the square, normalised onto the circle.
 RT_DEV void random_unit_vector_2d(Pcg &g, float &ox, float &oy) {
     while (true) {
-        float x = rnd(g) * 2.0f - 1.0f;
-        float y = rnd(g) * 2.0f - 1.0f;
+        float x = rnd_signed(g);
+        float y = rnd_signed(g);
         float len_sq = x * x + y * y;
         if (RT_MIN_LEN_SQ < len_sq && len_sq <= 1.0f) {
             float inv = __builtin_amdgcn_rsqf(len_sq);
@@ -101,9 +105,9 @@ RT_DEV void random_unit_vector_2d(Pcg &g, float &ox, float &oy) {
 // RayTracingKit/Vector3D.swift:113-127 (RNG.h:70-80 forgets z*z in the length).
 RT_DEV f3 random_unit_vector_3d(Pcg &g) {
     while (true) {
-        float x = rnd(g) * 2.0f - 1.0f;
-        float y = rnd(g) * 2.0f - 1.0f;
-        float z = rnd(g) * 2.0f - 1.0f;
+        float x = rnd_signed(g);
+        float y = rnd_signed(g);
+        float z = rnd_signed(g);
         float len_sq = fmaf(x, x, fmaf(y, y, z * z));
         if (RT_MIN_LEN_SQ < len_sq && len_sq <= 1.0f) {
             float inv = __builtin_amdgcn_rsqf(len_sq);
