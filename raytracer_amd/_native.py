@@ -30,6 +30,9 @@ def _load():
         raise ImportError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C raytracer_amd/csrc).  There is no fallback path." % LIB_PATH)
+    # torch carries its own copy of the HIP runtime; it has to be in the process first so that this
+    # library binds to the same one (two runtimes in one process cannot both open the device)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, u32, u64, f32 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float
     sig = {
