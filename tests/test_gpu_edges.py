@@ -126,6 +126,29 @@ def test_half_precision_nodes_render_the_same_image(ctx, make):
     assert close > 0.999          # a path that meets an exact tie between two objects may take the other one
 
 
+def test_half_precision_nodes_beyond_their_range(ctx):
+    """Box planes beyond 65504 become +-inf halves (or the float nodes are used when the choice
+    is left to the library): the image stays the one the float nodes give."""
+    from raytracer_amd.renderer import Renderer
+    m = ColoredLambertian((0.6, 0.6, 0.6))
+    scene = Scene(CameraConfig(vertical_fov=40, look_from=(0, 2, 8), look_at=(0, 0.5, 0)), [
+        Sphere((0, -2.0e5, 0), 2.0e5, m),                     # ground: box planes at +-2e5 and -4e5
+        Sphere((0, 0.5, 0), 0.5, ColoredLambertian((0.8, 0.2, 0.2))),
+        Sphere((1.2, 0.4, 0.5), 0.4, m), Sphere((-1.1, 0.3, 0.8), 0.3, m),
+        Sphere((7.0e4, 0.5, -3.0e5), 2.0e4, m),              # far object, everything out of range
+    ])
+    imgs = []
+    for fmt in (abi.RT_NODES_F32, abi.RT_NODES_F16, abi.RT_NODES_AUTO):
+        r = Renderer(scene, 160, 90, ctx=ctx, nodes=fmt)
+        r.draw(8, 12, 2)
+        torch.cuda.synchronize()
+        imgs.append(r.accum.clone())
+    assert torch.isfinite(imgs[1]).all()
+    scale = max(1.0, imgs[0].abs().max().item())
+    for other in imgs[1:]:
+        assert ((imgs[0] - other).abs() <= 1e-4 * scale).float().mean().item() > 0.999
+
+
 def _interval_mismatches(nat, sid, orc, oid, rays, scripted=None, key=0):
     got = nat.intervals(sid, rays, scripted=scripted, volume_key=key)
     bad = 0
