@@ -5,8 +5,8 @@
 //
 //  * wavefront: k_wf_raygen -> { k_wf_extend -> k_wf_shade } x max_depth -> k_wf_accumulate.
 //    Path state is SoA float4 streams in HBM (80 B per path).  Shade compacts the
-//    surviving paths into the other queue with one ballot + one atomic per wave, so every
-//    extend launch runs on dense waves.  Finished samples are written to a per-sample
+//    surviving paths into the other queue (eight shards, ballots + one atomic per
+//    workgroup), so every extend launch runs on dense waves.  Finished samples are written to a per-sample
 //    slot and summed per pixel by the accumulate kernel: no scattered float atomics.
 //
 //  * fused: k_fused, one persistent kernel.  A wave owns an 8x8 pixel tile for a chunk of
