@@ -134,6 +134,35 @@ class ImageTexture:
         assert self.pixels.ndim == 3 and self.pixels.shape[2] == 3
 
     @staticmethod
+    def load(name, bundle_dirs=()):
+        """TextureLoader.doLoad, Texture.swift:29-41: the file `name` from the first directory
+        that has it, decoded to 8-bit RGB (the reference decodes with MTKTextureLoader /
+        CoreGraphics, here PIL does); the placeholder when no directory has it or it does not
+        decode.  Rows are kept top to bottom; the bottom-left origin the loader asks for is
+        what the samplers apply."""
+        import os
+        for d in bundle_dirs:
+            path = os.path.join(d, name)
+            if os.path.isfile(path):
+                try:
+                    from PIL import Image
+                    with Image.open(path) as im:
+                        return ImageTexture(name, np.asarray(im.convert("RGB"), dtype=np.uint8))
+                except Exception:      # the reference falls back to the placeholder on any loader error (:38-40)
+                    break
+        return ImageTexture(name)
+
+    @staticmethod
+    def bundled(name, width, height, seed, texture_dir=None):
+        """The bundled image `name` when `texture_dir` holds it, a procedural stand-in of the
+        given size otherwise (the reference's JPEGs do not travel with this repository)."""
+        if texture_dir:
+            t = ImageTexture.load(name, [texture_dir])
+            if t.pixels.shape[:2] != (1, 1):
+                return t
+        return ImageTexture.procedural(name, width, height, seed)
+
+    @staticmethod
     def procedural(name, width, height, seed):
         """Checker-gradient RGB8 image from WyRand(seed): synthetic stand-in for the JPEGs."""
         r = wyrand_block(seed, 64)

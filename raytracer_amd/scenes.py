@@ -56,18 +56,19 @@ def simple_cylinders():
     ])
 
 
-def textured_cylinders(seed=5):
-    """Scene.swift:80-119 with procedural images in place of the bundled JPEGs."""
+def textured_cylinders(seed=5, texture_dir=None):
+    """Scene.swift:80-119; the bundled JPEGs from `texture_dir` (MetalRayTracer/Textures) when
+    given, procedural images of the same sizes otherwise."""
     ground = ColoredLambertian((1.8, 1.8, 1.0))
     left = Dielectric(1.50)
     right = ColoredMetal((0.8, 0.6, 0.2), 0.1)
-    tex = lambda name, w, h, k: TexturedLambertian(ImageTexture.procedural(name, w, h, seed + k))
+    tex = lambda name, w, h, k: TexturedLambertian(ImageTexture.bundled(name, w, h, seed + k, texture_dir))
     return Scene(CameraConfig(), [
         Cylinder(T.translate(-0.5, 0, -1) * T.rotation_deg(90, "x") * T.translate(0, -0.3, 0), 0.2, 0.6, left),
         Cylinder(T.translate(0, -0.2, -1.2), 0.2, 0.4,
-                 bottom=tex("barrel-bottom.jpg", 64, 64, 0), top=tex("barrel-top.jpg", 64, 64, 1),
-                 side=tex("barrel-side.jpg", 256, 128, 2)),
-        Sphere((0, 0.8, -1.2), 0.3, tex("earthmap.jpg", 256, 128, 3)),
+                 bottom=tex("barrel-bottom.jpg", 192, 192, 0), top=tex("barrel-top.jpg", 192, 192, 1),
+                 side=tex("barrel-side.jpg", 512, 320, 2)),
+        Sphere((0, 0.8, -1.2), 0.3, tex("earthmap.jpg", 1024, 512, 3)),
         Cylinder(T.translate(+0.5, 0, -1) * T.rotation_deg(90, "z") * T.translate(0, -0.2, 0), 0.2, 0.4, right),
         Sphere((0, -100.5, -1), 100, ground),
     ])
@@ -223,14 +224,15 @@ def bouncing_spheres(seed=1):
     return Scene(base.camera, objs)
 
 
-def kit_world1(seed=3):
+def kit_world1(seed=3, texture_dir=None):
     """makeWorld1 of the command-line renderer (RayTracing/main.swift:11-104) with the Kit's
     own textures: an earth-like image on a tilted sphere, three barrels whose caps and
     side are windows of one 512x512 image (bilinear, the side window mirrored in v), a
     glass lens as an intersection of two spheres, a ceiling light, a mirror ball and two
-    coloured quads.  Procedural images stand in for the bundled JPEGs."""
-    earth = ImageTexture.procedural("kit-earthmap", 512, 256, seed)
-    barrel = ImageTexture.procedural("kit-barrel", 512, 512, seed + 1)
+    coloured quads.  `texture_dir` (RayTracing/textures) supplies the bundled JPEGs; procedural
+    images of the same sizes stand in without it."""
+    earth = ImageTexture.bundled("earthmap.jpg", 1024, 512, seed, texture_dir)
+    barrel = ImageTexture.bundled("barrel.jpg", 512, 512, seed + 1, texture_dir)
     glass = Dielectric(1.5)
     lens = Transformed(Transform.translate(-0.5, 0, 0) * Transform.rotation_deg(-45, "y"),
                        Intersection(Sphere((0, 1, -9.915), 10.0, glass), Sphere((0, 1, 9.915), 10.0, glass)))

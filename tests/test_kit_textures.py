@@ -228,3 +228,61 @@ def test_kit_worlds_render_like_the_oracle(ctx, make):
     out.draw(4, 8, 1)
     rgb = out.image_rgb8()
     assert image.read_ppm_text(image.ppm_text(rgb)).shape == (36, 64, 3)
+
+
+# ---------------------------------------------------------------- image files
+def test_image_loader_decodes_png_and_jpeg_and_falls_back(tmp_path):
+    """TextureLoader.doLoad (MetalRayTracer/Texture.swift:29-41) / Image.load (Image.swift:120-129)."""
+    from PIL import Image as PILImage
+    rs = np.random.RandomState(1)
+    px = rs.randint(0, 256, size=(12, 20, 3)).astype(np.uint8)
+    PILImage.fromarray(px).save(os.path.join(str(tmp_path), "exact.png"))
+    t = ImageTexture.load("exact.png", [str(tmp_path)])
+    assert np.array_equal(t.pixels, px)                       # lossless, rows top to bottom
+    smooth = np.zeros((32, 48, 3), dtype=np.uint8)
+    smooth[..., 0] = np.linspace(0, 255, 48)[None, :]
+    smooth[..., 1] = np.linspace(0, 255, 32)[:, None]
+    PILImage.fromarray(smooth).save(os.path.join(str(tmp_path), "smooth.jpg"), quality=95)
+    j = ImageTexture.load("smooth.jpg", ["/nonexistent", str(tmp_path)])
+    assert j.pixels.shape == (32, 48, 3) and np.abs(j.pixels.astype(int) - smooth.astype(int)).mean() < 3
+    missing = ImageTexture.load("nope.jpg", [str(tmp_path)])
+    assert missing.pixels.shape == (1, 1, 3) and list(missing.pixels[0, 0]) == [255, 0, 255]     # magenta placeholder, :43-54
+    open(os.path.join(str(tmp_path), "broken.jpg"), "wb").write(b"not a jpeg")
+    assert ImageTexture.load("broken.jpg", [str(tmp_path)]).pixels.shape == (1, 1, 3)
+    assert ImageTexture.bundled("nope.jpg", 16, 8, 3, str(tmp_path)).pixels.shape == (8, 16, 3)
+
+
+REF_TEXTURES = "/root/reference/RayTracing/textures"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_TEXTURES), reason="the reference's bundled JPEGs are not on this machine")
+def test_kit_world1_with_the_bundled_jpegs():
+    """With the reference's own earthmap.jpg / barrel.jpg the barrel windows of
+    RayTracing/main.swift:53-55 stay inside the 512x512 image and the scene flattens."""
+    scene = scenes.kit_world1(texture_dir=REF_TEXTURES)
+    orc = ob.oracle_scene_from(scene)
+    img, _, _ = orc.render(scene.camera, RenderConfig(1, 6, 1, 2, 0), 32, 18)
+    assert np.isfinite(img).all() and img.max() > 0
+    from raytracer_amd._native import lib
+    h = C.c_void_p()
+    assert lib.rt_scene_create(None, C.byref(h)) == 0
+
+    class Sink:
+        def __getattr__(self, fn):
+            def call(*args):
+                if fn == "add_material":
+                    rc = lib.rt_add_material(h, C.byref(args[0]), C.sizeof(args[0]))
+                elif fn == "add_texture_rgb8":
+                    rc = lib.rt_add_texture_rgb8(h, args[0], args[1], np.ascontiguousarray(args[2]).ctypes.data_as(C.c_void_p))
+                elif fn == "shape_csg":
+                    arr = (C.c_int * len(args[1]))(*args[1])
+                    rc = lib.rt_shape_csg(h, args[0], len(args[1]), arr)
+                elif fn == "add_object":
+                    rc = lib.rt_add_object(h, args[0])
+                else:
+                    rc = getattr(lib, "rt_" + fn)(h, C.byref(args[0]))
+                assert rc >= 0, (fn, lib.rt_last_error())
+                return rc
+            return call
+    scene.encode(Sink())
+    lib.rt_scene_destroy(h)
