@@ -730,9 +730,15 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS, NODE16>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
     int grid = device_cus() * occ;
-    // enough work items that the dynamic queue evens out the waves: >= 8 per resident wave
-    uint32_t want_items = (uint32_t)grid * RT_WAVES * 8u;
-    uint32_t n_chunks = std::max(1u, std::min((want_items + n_tiles - 1u) / n_tiles, std::max(1u, rc.spp / 16u)));
+    // Work items = tiles x sample chunks.  Small chunks cost a ramp-up and a drain of the wave per
+    // item, large ones leave the waves finishing at different times at the end of the launch
+    // (with 3 chunks per tile that tail was 15 % of a 1024-spp launch): chunks of about 48 samples
+    // per pixel, more of them while that gives fewer than 48 items per resident wave, never below
+    // 8 samples per pixel.
+    const uint32_t target = 48u, min_chunk = 8u;
+    uint32_t want_items = (uint32_t)grid * RT_WAVES * 48u;
+    uint32_t n_chunks = std::max((rc.spp + target / 2u) / target, (want_items + n_tiles - 1u) / n_tiles);
+    n_chunks = std::max(1u, std::min(n_chunks, std::max(1u, rc.spp / min_chunk)));
     uint32_t chunk_spp = (rc.spp + n_chunks - 1u) / n_chunks;
     n_chunks = (rc.spp + chunk_spp - 1u) / chunk_spp;
     uint32_t n_items = n_tiles * n_chunks;
