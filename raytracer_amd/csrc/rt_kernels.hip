@@ -9,10 +9,11 @@
 //    workgroup), so every extend launch runs on dense waves.  Finished samples are written to a per-sample
 //    slot and summed per pixel by the accumulate kernel: no scattered float atomics.
 //
-//  * fused: k_fused, one persistent kernel.  A wave owns an 8x8 pixel tile for a chunk of
-//    samples and runs raygen / extend / shade as wave-wide phases; a lane whose path ended
-//    takes the tile's next (pixel, sample) at once, so lanes stay busy while path state
-//    never leaves registers.  Tile sums are kept in LDS and flushed once per work item.
+//  * fused: k_fused, one persistent kernel.  A wave works on an 8x8 pixel tile for a chunk of
+//    samples at a time and runs raygen / extend / shade as wave-wide phases; a lane whose path
+//    ended takes the next (pixel, sample) at once - of the current item or, when that is used
+//    up, of the next one - so lanes stay busy while path state never leaves registers.  Tile
+//    sums are kept in LDS and flushed once per work item.
 //
 // Both draw sample s of pixel (x, y) from the same generator stream, so they are the same
 // estimator sample for sample.
@@ -434,6 +435,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_accumulate(const float4 *sample
 // across the excursion.  Shading therefore runs on a quarter-full wave at worst and
 // traversal never drops below three quarters of the lanes that hold a path.
 
+// The camera lives in the workspace (RT_FUSED_CAMERA_OFFSET) instead of the kernel's argument
+// registers: only ray generation reads it, and two dozen scalar registers held for the whole
+// kernel made the compiler spill scalars inside the traversal loops.
+#define RT_FUSED_CAMERA_OFFSET 2048u
+__global__ void k_fused_setup(uint32_t *workspace, RtDevCamera cam) {
+    for (uint32_t i = threadIdx.x; i < RT_FUSED_CAMERA_OFFSET / 4u; i += blockDim.x) workspace[i] = 0u;   // work counter, diagnostics
+    if (threadIdx.x == 0) *(RtDevCamera *)((char *)workspace + RT_FUSED_CAMERA_OFFSET) = cam;
+}
+
 // PROF = true is a diagnostic build: it counts, per phase, wave-level executions, the lanes
 // that took part, and shader cycles, into 16 words behind the work counter.  Its run time
 // means nothing (the stamps serialise the phases).
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_accumulate(const float4 *sample
 // cylinders, boxes, quads, CSG shapes or volumes at 4 (128 VGPRs: at 96 their leaf tests
 // spill and run at half the rate).
 template <int FEAT, bool PROF, int STACK, int WPS, bool NODE16>
-__global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, RtDevCamera cam, RtDevRender rc, float *accum,
+__global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtDevCamera *camp, uint32_t background, RtDevRender rc, float *accum,
                                                      uint32_t *counter, uint32_t n_items, uint32_t tiles_x,
                                                      uint32_t n_tiles, uint32_t chunk_spp, uint32_t knobs) {
     __shared__ uint32_t stack_mem[STACK * RT_BLOCK];
@@ -460,116 +470,140 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, RtDevCame
     unsigned long long stamp = 0;
 #define RT_PROF_BEGIN() do { if (PROF) stamp = __builtin_amdgcn_s_memtime(); } while (0)
 #define RT_PROF_END(k, cond) do { if (PROF) { unsigned long long m_ = __ballot(cond); if (m_) { pc[3 * (k)] += 1; pc[3 * (k) + 1] += __popcll(m_); pc[3 * (k) + 2] += __builtin_amdgcn_s_memtime() - stamp; } } } while (0)
+    // Work items (an 8x8 tile x a chunk of samples) are streamed: when the current item has
+    // handed out its last sample the wave takes the next one at once and the free lanes go on
+    // with it, while the lanes still walking paths of earlier items finish those on the side.
+    // The tile sums in LDS always belong to the current item: they are flushed when the wave
+    // moves on, and a straggler adds its radiance to memory itself ("direct").
+    uint32_t next = 0, total = 0, tx0 = 0, ty0 = 0, s_begin = 0;
+    bool more = true;                  // the item counter has not run out yet
+    bool has_path = false, direct = false;
+    f3 thr = mk3(0, 0, 0), rad = mk3(0, 0, 0);
+    uint32_t depth = 0, pxy = 0;       // pixel of the lane's path: x | y << 16
+    uint64_t key = 0;
+    float time = 0.f;                  // the sample's time; only scenes with moving objects draw one
+    Pcg g;
+    g.state = g.inc = 0;
+    Trav t;
+    trav_begin(t, RT_REF_NONE, mk3(0, 0, 0), mk3(0, 0, 1), RT_INF);
+    acc[lane] = 0.f; acc[lane + 64] = 0.f; acc[lane + 128] = 0.f;
     while (true) {
-        uint32_t item = 0;
-        if (lane == 0) item = atomicAdd(counter, 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) break;              // every wave reaches this: the grid drains
-        const uint32_t tile = item % n_tiles, chunk = item / n_tiles;
-        const uint32_t s_begin = chunk * chunk_spp;
-        const uint32_t s_end = min(rc.spp, s_begin + chunk_spp);
-        const uint32_t total = (s_end - s_begin) * 64u;
-        const uint32_t tx0 = (tile % tiles_x) * 8u, ty0 = (tile / tiles_x) * 8u;
-        acc[lane] = 0.f; acc[lane + 64] = 0.f; acc[lane + 128] = 0.f;
-        uint32_t next = 0;
-        bool has_path = false;
-        f3 thr = mk3(0, 0, 0), rad = mk3(0, 0, 0);
-        uint32_t depth = 0, pix = 0;
-        uint64_t key = 0;
-        float time = 0.f;               // the sample's time; only scenes with moving objects draw one
-        Pcg g;
-        g.state = g.inc = 0;
-        Trav t;
-        trav_begin(t, RT_REF_NONE, mk3(0, 0, 0), mk3(0, 0, 1), RT_INF);
-        while (true) {
-            // ---- shade phase: lanes whose traversal ended
-            bool start = false;
-            f3 o = t.o, d = t.d;
-            RT_PROF_BEGIN();
-            const bool shading = has_path && t.cur == RT_REF_NONE;
-            if (has_path && t.cur == RT_REF_NONE) {
-                bool alive = shade_path<FEAT>(s, cam.background, rc.max_depth, t.found, t.best, o, d, thr, rad, depth, g, time);
-                if (alive) {
-                    start = true;
+        // ---- shade phase: lanes whose traversal ended
+        bool start = false;
+        f3 o = t.o, d = t.d;
+        RT_PROF_BEGIN();
+        const bool shading = has_path && t.cur == RT_REF_NONE;
+        if (has_path && t.cur == RT_REF_NONE) {
+            bool alive = shade_path<FEAT>(s, background, rc.max_depth, t.found, t.best, o, d, thr, rad, depth, g, time);
+            if (alive) {
+                start = true;
+            } else {
+                // accumulate phase
+                const uint32_t x = pxy & 0xFFFFu, y = pxy >> 16;
+                if (direct) {
+                    float *dst = accum + 3 * ((size_t)y * rc.width + x);
+                    atomicAdd(dst + 0, rad.x);
+                    atomicAdd(dst + 1, rad.y);
+                    atomicAdd(dst + 2, rad.z);
                 } else {
-                    // accumulate phase (LDS atomics: lanes of the wave may share a pixel)
+                    // LDS atomics: lanes of the wave may share a pixel
+                    const uint32_t pix = (x - tx0) + 8u * (y - ty0);
                     atomicAdd(&acc[3u * pix + 0u], rad.x);
                     atomicAdd(&acc[3u * pix + 1u], rad.y);
                     atomicAdd(&acc[3u * pix + 2u], rad.z);
-                    has_path = false;
                 }
-            }
-            RT_PROF_END(0, shading);
-            RT_PROF_BEGIN();
-            const bool generating = !has_path && next < total;
-            // ---- raygen phase: lanes without a path take the tile's next samples
-            if (next < total) {
-                uint64_t need = __ballot(!has_path);
-                if (!has_path) {
-                    uint32_t k = next + prefix_rank(need);
-                    if (k < total) {
-                        pix = k & 63u;
-                        uint32_t x = tx0 + (pix & 7u), y = ty0 + (pix >> 3);
-                        if (x < rc.width && y < rc.height) {
-                            g = sample_stream(seed, rc.first_sample + s_begin + (k >> 6), x, y);
-                            camera_ray(cam, x, y, g, o, d);
-                            if (FEAT & RT_FEAT_MOTION) time = rnd(g);
-                            thr = mk3(1, 1, 1);
-                            rad = mk3(0, 0, 0);
-                            depth = 0;
-                            has_path = true;
-                            start = true;
-                        }
-                    }
-                }
-                next += (uint32_t)__popcll(need);
-            }
-            RT_PROF_END(1, generating);
-            if (start) {
-                key = g.state;
-                trav_begin(t, s.root, o, d, RT_INF);
-            }
-            const uint32_t n_paths = (uint32_t)__popcll(__ballot(has_path));
-            if (n_paths == 0) {
-                if (next >= total) break;
-                continue;
-            }
-            // ---- extend phase
-            while (true) {
-                // node steps go on while enough lanes sit on inner nodes; once fewer than
-                // node_min do and some lane waits at a leaf, the leaf tests get their turn
-                while (true) {
-                    bool inner = !(t.cur & RT_REF_LEAF);
-                    uint32_t n_inner = (uint32_t)__popcll(__ballot(inner));
-                    if (n_inner == 0) break;
-                    if (n_inner < node_min && __ballot(!inner && t.cur != RT_REF_NONE)) break;
-                    RT_PROF_BEGIN();
-                    if (inner) {
-                        if (NODE16) trav_node16(nodes16, t, RT_T_MIN, stack);
-                        else trav_node(nodes, t, RT_T_MIN, stack);
-                    }
-                    RT_PROF_END(2, inner);
-                }
-                RT_PROF_BEGIN();
-                const bool at_leaf = (t.cur & RT_REF_LEAF) && t.cur != RT_REF_NONE;
-                if (at_leaf) {
-                    test_object<SIMPLE, (FEAT & RT_FEAT_MOTION) != 0>(s, t.cur & ~RT_REF_LEAF, t.o, t.d, RT_T_MIN, RT_INF, key, nullptr, 0, t.found, t.best, time);
-                    trav_pop(t, stack);
-                }
-                RT_PROF_END(3, at_leaf);
-                uint32_t n_active = (uint32_t)__popcll(__ballot(t.cur != RT_REF_NONE));
-                if (n_active == 0 || n_paths - n_active >= refill) break;
+                has_path = false;
             }
         }
-        // flush the tile (other chunks of the same tile may be in flight elsewhere)
-        {
-            uint32_t x = tx0 + (lane & 7u), y = ty0 + (lane >> 3);
-            if (x < rc.width && y < rc.height) {
-                float *dst = accum + 3 * ((size_t)y * rc.width + x);
-                atomicAdd(dst + 0, acc[3u * lane + 0u]);
-                atomicAdd(dst + 1, acc[3u * lane + 1u]);
-                atomicAdd(dst + 2, acc[3u * lane + 2u]);
+        RT_PROF_END(0, shading);
+        // ---- the current item is used up: flush its sums and take the next one
+        if (next >= total && more) {
+            if (total) {
+                uint32_t x = tx0 + (lane & 7u), y = ty0 + (lane >> 3);
+                if (x < rc.width && y < rc.height) {
+                    // other chunks of the same tile may be in flight elsewhere: atomics
+                    float *dst = accum + 3 * ((size_t)y * rc.width + x);
+                    atomicAdd(dst + 0, acc[3u * lane + 0u]);
+                    atomicAdd(dst + 1, acc[3u * lane + 1u]);
+                    atomicAdd(dst + 2, acc[3u * lane + 2u]);
+                }
+                acc[lane] = 0.f; acc[lane + 64] = 0.f; acc[lane + 128] = 0.f;
             }
+            direct = direct || has_path;
+            uint32_t item = 0;
+            if (lane == 0) item = atomicAdd(counter, 1u);
+            item = __builtin_amdgcn_readfirstlane(item);
+            next = total = 0;
+            if (item >= n_items) {
+                more = false;                    // every wave gets here: the grid drains
+            } else {
+                const uint32_t tile = item % n_tiles, chunk = item / n_tiles;
+                s_begin = chunk * chunk_spp;
+                total = (min(rc.spp, s_begin + chunk_spp) - s_begin) * 64u;
+                tx0 = (tile % tiles_x) * 8u;
+                ty0 = (tile / tiles_x) * 8u;
+            }
+        }
+        RT_PROF_BEGIN();
+        const bool generating = !has_path && next < total;
+        // ---- raygen phase: lanes without a path take the item's next samples
+        if (next < total) {
+            uint64_t need = __ballot(!has_path);
+            if (!has_path) {
+                uint32_t k = next + prefix_rank(need);
+                if (k < total) {
+                    uint32_t x = tx0 + (k & 7u), y = ty0 + ((k >> 3) & 7u);
+                    if (x < rc.width && y < rc.height) {
+                        g = sample_stream(seed, rc.first_sample + s_begin + (k >> 6), x, y);
+                        camera_ray(*camp, x, y, g, o, d);
+                        if (FEAT & RT_FEAT_MOTION) time = rnd(g);
+                        thr = mk3(1, 1, 1);
+                        rad = mk3(0, 0, 0);
+                        depth = 0;
+                        pxy = x | (y << 16);
+                        direct = false;
+                        has_path = true;
+                        start = true;
+                    }
+                }
+            }
+            next += (uint32_t)__popcll(need);
+        }
+        RT_PROF_END(1, generating);
+        if (start) {
+            key = g.state;
+            trav_begin(t, s.root, o, d, RT_INF);
+        }
+        const uint32_t n_paths = (uint32_t)__popcll(__ballot(has_path));
+        if (n_paths == 0) {
+            if (!more && next >= total) break;       // nothing left to hand out, nothing in flight
+            continue;
+        }
+        // ---- extend phase
+        while (true) {
+            // node steps go on while enough lanes sit on inner nodes; once fewer than
+            // node_min do and some lane waits at a leaf, the leaf tests get their turn
+            while (true) {
+                bool inner = !(t.cur & RT_REF_LEAF);
+                uint32_t n_inner = (uint32_t)__popcll(__ballot(inner));
+                if (n_inner == 0) break;
+                if (n_inner < node_min && __ballot(!inner && t.cur != RT_REF_NONE)) break;
+                RT_PROF_BEGIN();
+                if (inner) {
+                    if (NODE16) trav_node16(nodes16, t, RT_T_MIN, stack);
+                    else trav_node(nodes, t, RT_T_MIN, stack);
+                }
+                RT_PROF_END(2, inner);
+            }
+            RT_PROF_BEGIN();
+            const bool at_leaf = (t.cur & RT_REF_LEAF) && t.cur != RT_REF_NONE;
+            if (at_leaf) {
+                test_object<SIMPLE, (FEAT & RT_FEAT_MOTION) != 0>(s, t.cur & ~RT_REF_LEAF, t.o, t.d, RT_T_MIN, RT_INF, key, nullptr, 0, t.found, t.best, time);
+                trav_pop(t, stack);
+            }
+            RT_PROF_END(3, at_leaf);
+            uint32_t n_active = (uint32_t)__popcll(__ballot(t.cur != RT_REF_NONE));
+            if (n_active == 0 || n_paths - n_active >= refill) break;
         }
     }
     if (PROF && lane == 0) {
@@ -730,13 +764,13 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS, NODE16>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
     int grid = device_cus() * occ;
-    // Work items = tiles x sample chunks.  Small chunks cost a ramp-up and a drain of the wave per
-    // item, large ones leave the waves finishing at different times at the end of the launch
-    // (with 3 chunks per tile that tail was 15 % of a 1024-spp launch): chunks of about 48 samples
-    // per pixel, more of them while that gives fewer than 48 items per resident wave, never below
-    // 8 samples per pixel.
-    const uint32_t target = 48u, min_chunk = 8u;
-    uint32_t want_items = (uint32_t)grid * RT_WAVES * 48u;
+    // Work items = tiles x sample chunks.  Large chunks leave the waves finishing at different
+    // times at the end of the launch (with 3 chunks per tile that tail was 15 % of a 1024-spp
+    // launch); small ones only cost a flush of the tile sums each, since a wave streams from one
+    // item into the next: chunks of about 32 samples per pixel, more of them while that gives
+    // fewer than 96 items per resident wave, never below 4 samples per pixel.
+    const uint32_t target = 32u, min_chunk = 4u;
+    uint32_t want_items = (uint32_t)grid * RT_WAVES * 96u;
     uint32_t n_chunks = std::max((rc.spp + target / 2u) / target, (want_items + n_tiles - 1u) / n_tiles);
     n_chunks = std::max(1u, std::min(n_chunks, std::max(1u, rc.spp / min_chunk)));
     uint32_t chunk_spp = (rc.spp + n_chunks - 1u) / n_chunks;
@@ -744,13 +778,15 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     uint32_t n_items = n_tiles * n_chunks;
     grid = (int)std::min<uint32_t>((uint32_t)grid, (n_items + RT_WAVES - 1u) / RT_WAVES);
     const bool prof = (knobs & 0x10000u) != 0;
-    hipError_t e = hipMemsetAsync(counter, 0, prof ? 512 : 256, stream);
+    k_fused_setup<<<1, 256, 0, stream>>>(counter, cam);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    const RtDevCamera *camp = (const RtDevCamera *)((const char *)counter + RT_FUSED_CAMERA_OFFSET);
     if (timer) timer->begin(stream);
     if (prof)
-        k_fused<FEAT, true, STACK, WPS, NODE16><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
+        k_fused<FEAT, true, STACK, WPS, NODE16><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
     else
-        k_fused<FEAT, false, STACK, WPS, NODE16><<<grid, RT_BLOCK, 0, stream>>>(s, cam, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
+        k_fused<FEAT, false, STACK, WPS, NODE16><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
     if (timer) timer->end(stream);
     return hipGetLastError();
 }
