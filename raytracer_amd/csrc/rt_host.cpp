@@ -1155,7 +1155,7 @@ int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, i
         // scenes let node steps run on nearly empty waves so that the leaf tests find full ones
         const uint32_t node_min = sc->node_min >= 0 ? (uint32_t)sc->node_min : ((sc->feat & 1u) ? 8u : 32u);
         const uint32_t knobs = sc->refill | (node_min << 8) | (getenv("RT_PROFILE_PHASES") ? 0x10000u : 0u) |
-                               (sc->use_nodes16 ? 0x20000u : 0u);
+                               (sc->use_nodes16 ? 0x20000u : 0u) | ((cam.defocus ? 16u : 0u) << 18);
         e = rt_render_fused(sc->dev, sc->feat, sc->stats.bvh_depth, cam, r, knobs, accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);
     } else if (pipeline == RT_PIPELINE_WAVEFRONT) {
         if (workspace_bytes < rt_wavefront_bytes((uint32_t)width * (uint32_t)height))

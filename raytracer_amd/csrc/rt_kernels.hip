@@ -460,6 +460,9 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
     __shared__ float tile_acc[RT_WAVES][192];
     constexpr bool SIMPLE = !(FEAT & RT_FEAT_XPRIM);
     const uint32_t refill = knobs & 255u, node_min = (knobs >> 8) & 255u;
+    // Ray generation with a defocus disk (a rejection loop) costs about as much as six node steps:
+    // it waits until 16 lanes are free.  Without the disk it is cheap and free lanes are not left idle.
+    const uint32_t raygen_min = (knobs >> 18) & 127u;
     const uint32_t lane = lane_id();
     uint32_t *stack = stack_mem + threadIdx.x;
     float *acc = tile_acc[threadIdx.x >> 6];
@@ -547,8 +550,8 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
         RT_PROF_BEGIN();
         const bool generating = !has_path && next < total;
         // ---- raygen phase: lanes without a path take the item's next samples
-        if (next < total) {
-            uint64_t need = __ballot(!has_path);
+        const uint64_t need = __ballot(!has_path);
+        if (next < total && ((uint32_t)__popcll(need) >= raygen_min || __popcll(need) == 64)) {
             if (!has_path) {
                 uint32_t k = next + prefix_rank(need);
                 if (k < total) {
