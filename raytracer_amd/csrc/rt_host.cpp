@@ -80,7 +80,7 @@ struct RtScene {
     std::vector<float> bulk_spheres;       // cx, cy, cz, r
     std::vector<uint32_t> bulk_mats;
     int bvh_builder = RT_BVH_SAH;
-    uint32_t refill = 48;
+    uint32_t refill = 40;
     int node_min = -1;      // -1: chosen at render time from what the scene holds
     int node_format = RT_NODES_AUTO;
     float query_time = 0.f;     // time of rt_first_hit / rt_intervals queries
@@ -1153,7 +1153,7 @@ int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, i
         if (workspace_bytes < RT_FUSED_WORKSPACE) return fail(RT_ERR_INVALID, "workspace too small");
         // leaf tests of cylinders, boxes, CSG shapes and volumes cost several node steps: such
         // scenes let node steps run on nearly empty waves so that the leaf tests find full ones
-        const uint32_t node_min = sc->node_min >= 0 ? (uint32_t)sc->node_min : ((sc->feat & 1u) ? 8u : 32u);
+        const uint32_t node_min = sc->node_min >= 0 ? (uint32_t)sc->node_min : ((sc->feat & 1u) ? 8u : 16u);
         const uint32_t knobs = sc->refill | (node_min << 8) | (getenv("RT_PROFILE_PHASES") ? 0x10000u : 0u) |
                                (sc->use_nodes16 ? 0x20000u : 0u) | ((cam.defocus ? 16u : 0u) << 18);
         e = rt_render_fused(sc->dev, sc->feat, sc->stats.bvh_depth, cam, r, knobs, accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);

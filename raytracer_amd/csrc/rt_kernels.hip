@@ -429,11 +429,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_accumulate(const float4 *sample
 }
 
 // ------------------------------------------------------------------ fused persistent kernel
-// Lanes whose traversal has ended wait until at least `refill` (default 48) of them have, then the
+// Lanes whose traversal has ended wait until at least `refill` (default 40) of them have, then the
 // wave leaves the traversal loop, shades them (which usually starts their next bounce) and
 // hands fresh samples to lanes whose path ended; the others keep their traversal state
-// across the excursion.  Shading therefore runs on a quarter-full wave at worst and
-// traversal never drops below three quarters of the lanes that hold a path.
+// across the excursion.
 
 // The camera lives in the workspace (RT_FUSED_CAMERA_OFFSET) instead of the kernel's argument
 // registers: only ray generation reads it, and two dozen scalar registers held for the whole
