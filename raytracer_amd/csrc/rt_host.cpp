@@ -1151,11 +1151,13 @@ int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, i
     hipError_t e;
     if (pipeline == RT_PIPELINE_FUSED) {
         if (workspace_bytes < RT_FUSED_WORKSPACE) return fail(RT_ERR_INVALID, "workspace too small");
-        // leaf tests of cylinders, boxes, CSG shapes and volumes cost several node steps: such
-        // scenes let node steps run on nearly empty waves so that the leaf tests find full ones
-        const uint32_t node_min = sc->node_min >= 0 ? (uint32_t)sc->node_min : ((sc->feat & 1u) ? 8u : 16u);
+        // node steps go on while 8 lanes want one.  Sphere tests cost about one node step, so in
+        // sphere scenes 20 lanes waiting at a leaf get their turn even then; tests of cylinders,
+        // boxes, CSG shapes and volumes cost several node steps and wait for fuller waves
+        const uint32_t node_min = sc->node_min >= 0 ? (uint32_t)sc->node_min : 8u;
         const uint32_t knobs = sc->refill | (node_min << 8) | (getenv("RT_PROFILE_PHASES") ? 0x10000u : 0u) |
-                               (sc->use_nodes16 ? 0x20000u : 0u) | ((cam.defocus ? 16u : 0u) << 18);
+                               (sc->use_nodes16 ? 0x20000u : 0u) | ((cam.defocus ? 16u : 0u) << 18) |
+                               (((sc->feat & 1u) ? 65u : 20u) << 25);
         e = rt_render_fused(sc->dev, sc->feat, sc->stats.bvh_depth, cam, r, knobs, accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);
     } else if (pipeline == RT_PIPELINE_WAVEFRONT) {
         if (workspace_bytes < rt_wavefront_bytes((uint32_t)width * (uint32_t)height))

@@ -462,6 +462,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
     // Ray generation with a defocus disk (a rejection loop) costs about as much as six node steps:
     // it waits until 16 lanes are free.  Without the disk it is cheap and free lanes are not left idle.
     const uint32_t raygen_min = (knobs >> 18) & 127u;
+    const uint32_t leaf_max = (knobs >> 25) & 127u;
     const uint32_t lane = lane_id();
     uint32_t *stack = stack_mem + threadIdx.x;
     float *acc = tile_acc[threadIdx.x >> 6];
@@ -584,12 +585,14 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
         // ---- extend phase
         while (true) {
             // node steps go on while enough lanes sit on inner nodes; once fewer than
-            // node_min do and some lane waits at a leaf, the leaf tests get their turn
+            // node_min do and some lane waits at a leaf, or leaf_max lanes wait there, the
+            // leaf tests get their turn
             while (true) {
                 bool inner = !(t.cur & RT_REF_LEAF);
                 uint32_t n_inner = (uint32_t)__popcll(__ballot(inner));
                 if (n_inner == 0) break;
-                if (n_inner < node_min && __ballot(!inner && t.cur != RT_REF_NONE)) break;
+                const uint32_t n_leaf = (uint32_t)__popcll(__ballot(!inner && t.cur != RT_REF_NONE));
+                if ((n_inner < node_min && n_leaf) || n_leaf >= leaf_max) break;
                 RT_PROF_BEGIN();
                 if (inner) {
                     if (NODE16) trav_node16(nodes16, t, RT_T_MIN, stack);
