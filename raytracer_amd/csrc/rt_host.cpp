@@ -80,7 +80,7 @@ struct RtScene {
     std::vector<float> bulk_spheres;       // cx, cy, cz, r
     std::vector<uint32_t> bulk_mats;
     int bvh_builder = RT_BVH_SAH;
-    uint32_t refill = 40;
+    uint32_t refill = 48;
     int node_min = -1;      // -1: chosen at render time from what the scene holds
     int node_format = RT_NODES_AUTO;
     float query_time = 0.f;     // time of rt_first_hit / rt_intervals queries

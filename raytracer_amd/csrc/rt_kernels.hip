@@ -429,7 +429,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_accumulate(const float4 *sample
 }
 
 // ------------------------------------------------------------------ fused persistent kernel
-// Lanes whose traversal has ended wait until at least `refill` (default 40) of them have, then the
+// Lanes whose traversal has ended wait until at least `refill` (default 48) lanes are finished or free, then the
 // wave leaves the traversal loop, shades them (which usually starts their next bounce) and
 // hands fresh samples to lanes whose path ended; the others keep their traversal state
 // across the excursion.
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
             }
             RT_PROF_END(3, at_leaf);
             uint32_t n_active = (uint32_t)__popcll(__ballot(t.cur != RT_REF_NONE));
-            if (n_active == 0 || n_paths - n_active >= refill) break;
+            if (n_active == 0 || 64u - n_active >= refill) break;     // finished or free lanes
         }
     }
     if (PROF && lane == 0) {
