@@ -552,13 +552,22 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
         // ---- raygen phase: lanes without a path take the item's next samples
         const uint64_t need = __ballot(!has_path);
         if (next < total && ((uint32_t)__popcll(need) >= raygen_min || __popcll(need) == 64)) {
+            // The camera is read here, by scalar loads (it is constant while the kernel runs): the
+            // pointer is taken afresh each time so that the two dozen values live in scalar
+            // registers during ray generation only.
+            const RtDevCamera *cp = camp;
+            asm volatile("" : "+s"(cp));
+            const __attribute__((address_space(4))) uint32_t *cw = (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)cp;
+            RtDevCamera cam_now;
+#pragma unroll
+            for (uint32_t i = 0; i < sizeof(RtDevCamera) / 4u; i++) ((uint32_t *)&cam_now)[i] = cw[i];
             if (!has_path) {
                 uint32_t k = next + prefix_rank(need);
                 if (k < total) {
                     uint32_t x = tx0 + (k & 7u), y = ty0 + ((k >> 3) & 7u);
                     if (x < rc.width && y < rc.height) {
                         g = sample_stream(seed, rc.first_sample + s_begin + (k >> 6), x, y);
-                        camera_ray(*camp, x, y, g, o, d);
+                        camera_ray(cam_now, x, y, g, o, d);
                         if (FEAT & RT_FEAT_MOTION) time = rnd(g);
                         thr = mk3(1, 1, 1);
                         rad = mk3(0, 0, 0);

@@ -9,7 +9,7 @@ for d in sys.argv[1:]:
     for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         per = {}
         for row in csv.DictReader(open(path)):
-            if not row["Kernel_Name"].startswith(("k_fused", "void k_fused", "k_wf_extend", "void k_wf_extend")):
+            if not row["Kernel_Name"].startswith(("k_fused<", "void k_fused<", "k_wf_extend", "void k_wf_extend")):
                 continue
             per.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
             per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
