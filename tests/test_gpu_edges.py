@@ -126,6 +126,29 @@ def test_half_precision_nodes_render_the_same_image(ctx, make):
     assert close > 0.999          # a path that meets an exact tie between two objects may take the other one
 
 
+@pytest.mark.parametrize("size,spp", [((37, 19), 1), ((5, 3), 7), ((64, 8), 3), ((131, 77), 33)])
+def test_ragged_images_and_odd_sample_counts(ctx, size, spp):
+    """Partial 8x8 tiles, fewer pixels than one tile, sample counts that do not divide into
+    chunks: the fused kernel (streamed work items) and the wavefront pipeline (per-sample slots)
+    must add up the same samples."""
+    from raytracer_amd.renderer import Renderer
+    scene = scenes.simple_balls()
+    w, h = size
+    a = Renderer(scene, w, h, pipeline=abi.RT_PIPELINE_FUSED, ctx=ctx)
+    b = Renderer(scene, w, h, pipeline=abi.RT_PIPELINE_WAVEFRONT, ctx=ctx)
+    for r in (a, b):
+        r.draw(spp, 12, 21)
+        r.draw(spp, 12, 21)               # a second pass continues the sample stream
+    torch.cuda.synchronize()
+    x, y = a.accum, b.accum
+    assert torch.isfinite(x).all() and (x >= 0).all() and x.sum().item() > 0
+    assert (x - y).abs().max().item() <= 1e-4 * max(1.0, y.abs().max().item())
+    orc = ob.oracle_scene_from(scene)
+    ref, _, _ = orc.render(scene.camera, RenderConfig(2 * spp, 12, 1, 21, 0), w, h)
+    got = x.cpu().numpy().astype(np.float64)
+    assert np.mean(np.abs(got - ref) <= 1e-3 * (2 * spp)) > 0.9
+
+
 def test_half_precision_nodes_beyond_their_range(ctx):
     """Box planes beyond 65504 become +-inf halves (or the float nodes are used when the choice
     is left to the library): the image stays the one the float nodes give."""
