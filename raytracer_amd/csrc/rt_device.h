@@ -615,10 +615,31 @@ RT_DEV void trav_begin(Trav &t, uint32_t root, f3 o, f3 d, float tmax) {
     t.found = false;
 }
 
-RT_DEV void trav_pop(Trav &t, const uint32_t *stack) {
+// A kernel that wants more waves per SIMD than a full-depth LDS stack allows keeps only the
+// first LDS_ENTRIES entries of each lane's stack in LDS; deeper ones (rare: they need that many
+// levels with both children hit) go to a per-thread column in global memory,
+// deep[(entry - LDS_ENTRIES) * deep_stride].  LDS_ENTRIES = 0: the whole stack is in LDS.
+typedef __attribute__((address_space(1))) uint32_t global_u32;   // typed as global so that the two homes never share a flat access
+struct DeepStack {
+    global_u32 *column;    // already offset by the thread's index in the grid
+    uint32_t stride;       // threads in the grid
+};
+template <int LDS_ENTRIES>
+RT_DEV void stack_put(uint32_t *stack, const DeepStack *deep, int sp, uint32_t v) {
+    if (LDS_ENTRIES == 0 || sp < LDS_ENTRIES) stack[sp * RT_BLOCK] = v;
+    else deep->column[(size_t)(sp - LDS_ENTRIES) * deep->stride] = v;
+}
+template <int LDS_ENTRIES>
+RT_DEV uint32_t stack_get(const uint32_t *stack, const DeepStack *deep, int sp) {
+    if (LDS_ENTRIES == 0 || sp < LDS_ENTRIES) return stack[sp * RT_BLOCK];
+    return deep->column[(size_t)(sp - LDS_ENTRIES) * deep->stride];
+}
+
+template <int LDS_ENTRIES = 0>
+RT_DEV void trav_pop(Trav &t, const uint32_t *stack, const DeepStack *deep = nullptr) {
     if (t.sp == 0) { t.cur = RT_REF_NONE; return; }
     t.sp--;
-    t.cur = stack[t.sp * RT_BLOCK];
+    t.cur = stack_get<LDS_ENTRIES>(stack, deep, t.sp);
 }
 
 // Entry distance of the ray into one child box, and whether it is hit within
@@ -632,7 +653,8 @@ RT_DEV float box_entry(v2f tx, v2f ty, v2f tz, float tmin, float limit, bool &hi
 }
 
 // One inner-node step: tests both children, goes to the nearer one, pushes the farther.
-RT_DEV void trav_node(const float4 *nodes, Trav &t, float tmin, uint32_t *stack) {
+template <int LDS_ENTRIES = 0>
+RT_DEV void trav_node(const float4 *nodes, Trav &t, float tmin, uint32_t *stack, const DeepStack *deep = nullptr) {
     const float4 *n = nodes + 4u * t.cur;
     float4 a = n[0], b = n[1], c = n[2], e = n[3];
     v2f ix = {t.inv_d.x, t.inv_d.x}, iy = {t.inv_d.y, t.inv_d.y}, iz = {t.inv_d.z, t.inv_d.z};
@@ -648,7 +670,7 @@ RT_DEV void trav_node(const float4 *nodes, Trav &t, float tmin, uint32_t *stack)
     hr = hr && rref != RT_REF_NONE;       // a single-object scene has no right child
     if (hl && hr) {
         bool left_first = tl <= tr;
-        stack[t.sp * RT_BLOCK] = left_first ? rref : lref;
+        stack_put<LDS_ENTRIES>(stack, deep, t.sp, left_first ? rref : lref);
         t.sp++;
         t.cur = left_first ? lref : rref;
     } else if (hl) {
@@ -656,7 +678,7 @@ RT_DEV void trav_node(const float4 *nodes, Trav &t, float tmin, uint32_t *stack)
     } else if (hr) {
         t.cur = rref;
     } else {
-        trav_pop(t, stack);
+        trav_pop<LDS_ENTRIES>(t, stack, deep);
     }
 }
 
@@ -671,7 +693,8 @@ RT_DEV v2f slab_pair(uint32_t packed, float inv, float oid) {
     v2f r = {fmaf((float)h.x, inv, oid), fmaf((float)h.y, inv, oid)};
     return r;
 }
-RT_DEV void trav_node16(const uint4 *nodes16, Trav &t, float tmin, uint32_t *stack) {
+template <int LDS_ENTRIES = 0>
+RT_DEV void trav_node16(const uint4 *nodes16, Trav &t, float tmin, uint32_t *stack, const DeepStack *deep = nullptr) {
     const uint4 *n = nodes16 + 2u * t.cur;
     uint4 a = n[0], b = n[1];
     const bool px = t.inv_d.x >= 0.0f, py = t.inv_d.y >= 0.0f, pz = t.inv_d.z >= 0.0f;
@@ -687,7 +710,7 @@ RT_DEV void trav_node16(const uint4 *nodes16, Trav &t, float tmin, uint32_t *sta
     hr = hr && rref != RT_REF_NONE;
     if (hl && hr) {
         bool left_first = tl <= tr;
-        stack[t.sp * RT_BLOCK] = left_first ? rref : lref;
+        stack_put<LDS_ENTRIES>(stack, deep, t.sp, left_first ? rref : lref);
         t.sp++;
         t.cur = left_first ? lref : rref;
     } else if (hl) {
@@ -695,7 +718,7 @@ RT_DEV void trav_node16(const uint4 *nodes16, Trav &t, float tmin, uint32_t *sta
     } else if (hr) {
         t.cur = rref;
     } else {
-        trav_pop(t, stack);
+        trav_pop<LDS_ENTRIES>(t, stack, deep);
     }
 }
 

@@ -1134,7 +1134,7 @@ int rt_camera_rays(RtContext *ctx, const RtCameraConfig *cc, const RtRenderConfi
 
 size_t rt_render_workspace_size(int pipeline, int width, int height) {
     if (width <= 0 || height <= 0) return 0;
-    if (pipeline == RT_PIPELINE_FUSED) return RT_FUSED_WORKSPACE;
+    if (pipeline == RT_PIPELINE_FUSED) return rt_fused_workspace_bytes();
     return rt_wavefront_bytes((uint32_t)width * (uint32_t)height * RT_WAVEFRONT_BATCH_SPP);
 }
 
@@ -1150,7 +1150,7 @@ int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, i
     r.animated = (sc->feat & RT_FEAT_MOTION) ? 1u : 0u;
     hipError_t e;
     if (pipeline == RT_PIPELINE_FUSED) {
-        if (workspace_bytes < RT_FUSED_WORKSPACE) return fail(RT_ERR_INVALID, "workspace too small");
+        if (workspace_bytes < RT_FUSED_HEADER) return fail(RT_ERR_INVALID, "workspace too small");
         // node steps go on while 8 lanes want one.  Sphere tests cost about one node step, so in
         // sphere scenes 20 lanes waiting at a leaf get their turn even then; tests of cylinders,
         // boxes, CSG shapes and volumes cost several node steps and wait for fuller waves

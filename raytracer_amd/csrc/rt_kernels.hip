@@ -438,6 +438,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_accumulate(const float4 *sample
 // registers: only ray generation reads it, and two dozen scalar registers held for the whole
 // kernel made the compiler spill scalars inside the traversal loops.
 #define RT_FUSED_CAMERA_OFFSET 2048u
+#define RT_FUSED_DEEP_OFFSET 4096u
 __global__ void k_fused_setup(uint32_t *workspace, RtDevCamera cam) {
     for (uint32_t i = threadIdx.x; i < RT_FUSED_CAMERA_OFFSET / 4u; i += blockDim.x) workspace[i] = 0u;   // work counter, diagnostics
     if (threadIdx.x == 0) *(RtDevCamera *)((char *)workspace + RT_FUSED_CAMERA_OFFSET) = cam;
@@ -447,15 +448,22 @@ __global__ void k_fused_setup(uint32_t *workspace, RtDevCamera cam) {
 // that took part, and shader cycles, into 16 words behind the work counter.  Its run time
 // means nothing (the stamps serialise the phases).
 // STACK: LDS stack entries per lane; WPS: waves per SIMD the register allocation is bounded
-// for.  Spheres-only scenes whose BVH is at most 16 deep run at 8 waves per SIMD (64 VGPRs,
-// 19 KB of LDS per workgroup), other sphere scenes at 5 (96 VGPRs, 27 KB), scenes with
-// cylinders, boxes, quads, CSG shapes or volumes at 4 (128 VGPRs: at 96 their leaf tests
-// spill and run at half the rate).
-template <int FEAT, bool PROF, int STACK, int WPS, bool NODE16>
+// for.  Spheres-only scenes run at 8 waves per SIMD (64 VGPRs, 19 KB of LDS per workgroup: 16
+// stack entries per lane; a deeper tree keeps the entries beyond those in global memory),
+// textured sphere scenes at 5 (96 VGPRs, 27 KB), scenes with cylinders, boxes, quads, CSG
+// shapes or volumes at 4 (128 VGPRs: at 96 their leaf tests spill and run at half the rate).
+// DEEP: the tree may be deeper than STACK; entries from STACK up live in global memory behind
+// the workspace header (RT_FUSED_DEEP_OFFSET), one column per thread of the grid.
+template <int FEAT, bool PROF, int STACK, int WPS, bool NODE16, bool DEEP = false>
 __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtDevCamera *camp, uint32_t background, RtDevRender rc, float *accum,
                                                      uint32_t *counter, uint32_t n_items, uint32_t tiles_x,
                                                      uint32_t n_tiles, uint32_t chunk_spp, uint32_t knobs) {
     __shared__ uint32_t stack_mem[STACK * RT_BLOCK];
+    constexpr int LDS_ENTRIES = DEEP ? STACK : 0;
+    DeepStack deep_cols;
+    deep_cols.column = (global_u32 *)(uintptr_t)(counter + RT_FUSED_DEEP_OFFSET / 4u) + blockIdx.x * RT_BLOCK + threadIdx.x;
+    deep_cols.stride = gridDim.x * RT_BLOCK;
+    const DeepStack *deep = DEEP ? &deep_cols : nullptr;
     __shared__ float tile_acc[RT_WAVES][192];
     constexpr bool SIMPLE = !(FEAT & RT_FEAT_XPRIM);
     const uint32_t refill = knobs & 255u, node_min = (knobs >> 8) & 255u;
@@ -604,8 +612,8 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
                 if ((n_inner < node_min && n_leaf) || n_leaf >= leaf_max) break;
                 RT_PROF_BEGIN();
                 if (inner) {
-                    if (NODE16) trav_node16(nodes16, t, RT_T_MIN, stack);
-                    else trav_node(nodes, t, RT_T_MIN, stack);
+                    if (NODE16) trav_node16<LDS_ENTRIES>(nodes16, t, RT_T_MIN, stack, deep);
+                    else trav_node<LDS_ENTRIES>(nodes, t, RT_T_MIN, stack, deep);
                 }
                 RT_PROF_END(2, inner);
             }
@@ -613,7 +621,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
             const bool at_leaf = (t.cur & RT_REF_LEAF) && t.cur != RT_REF_NONE;
             if (at_leaf) {
                 test_object<SIMPLE, (FEAT & RT_FEAT_MOTION) != 0>(s, t.cur & ~RT_REF_LEAF, t.o, t.d, RT_T_MIN, RT_INF, key, nullptr, 0, t.found, t.best, time);
-                trav_pop(t, stack);
+                trav_pop<LDS_ENTRIES>(t, stack, deep);
             }
             RT_PROF_END(3, at_leaf);
             uint32_t n_active = (uint32_t)__popcll(__ballot(t.cur != RT_REF_NONE));
@@ -703,6 +711,12 @@ hipError_t rt_launch_progressive_present(const float *pass_sum, uint32_t spp, ui
     return hipGetLastError();
 }
 
+static int device_cus();
+// Header (work counter, diagnostics, camera) + the deep-stack columns of the largest grid.
+size_t rt_fused_workspace_bytes() {
+    return RT_FUSED_DEEP_OFFSET + (size_t)device_cus() * 8u * RT_BLOCK * (RT_STACK_DEPTH - 16) * 4u;
+}
+
 static int device_cus() {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -771,12 +785,12 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
     return hipSuccess;
 }
 
-template <int FEAT, int STACK, int WPS, bool NODE16>
+template <int FEAT, int STACK, int WPS, bool NODE16, bool DEEP = false>
 static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, const RtDevRender &rc, float *accum,
                                uint32_t *counter, uint32_t knobs, hipStream_t stream, RtKernelTimer *timer) {
     uint32_t tiles_x = (rc.width + 7u) / 8u, tiles_y = (rc.height + 7u) / 8u, n_tiles = tiles_x * tiles_y;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS, NODE16>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS, NODE16, DEEP>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
     int grid = device_cus() * occ;
     // Work items = tiles x sample chunks.  Large chunks leave the waves finishing at different
     // times at the end of the launch (with 3 chunks per tile that tail was 15 % of a 1024-spp
@@ -798,9 +812,9 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     const RtDevCamera *camp = (const RtDevCamera *)((const char *)counter + RT_FUSED_CAMERA_OFFSET);
     if (timer) timer->begin(stream);
     if (prof)
-        k_fused<FEAT, true, STACK, WPS, NODE16><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
+        k_fused<FEAT, true, STACK, WPS, NODE16, DEEP><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
     else
-        k_fused<FEAT, false, STACK, WPS, NODE16><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
+        k_fused<FEAT, false, STACK, WPS, NODE16, DEEP><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
     if (timer) timer->end(stream);
     return hipGetLastError();
 }
@@ -809,7 +823,7 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
                            uint32_t knobs, float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
                            RtKernelTimer *timer) {
     if (rc.width == 0 || rc.height == 0 || rc.spp == 0) return hipSuccess;
-    if (workspace_bytes < RT_FUSED_WORKSPACE) return hipErrorInvalidValue;
+    if (workspace_bytes < RT_FUSED_HEADER) return hipErrorInvalidValue;
     if (timer) timer->name = "k_fused";
     uint32_t *counter = (uint32_t *)workspace;
     const bool n16 = (knobs & 0x20000u) != 0 && s.nodes16 != nullptr;
@@ -818,6 +832,11 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
     switch (feat & 7u) {
     case 0:
         if (bvh_depth <= 16) return RT_FUSED(0, 16, 8);
+        // a deep tree (a million spheres) waits on memory, not on the ALUs: 8 waves per SIMD with
+        // the rare deep stack entries in global memory beat 5 waves with the whole stack in LDS
+        if (workspace_bytes >= rt_fused_workspace_bytes())
+            return n16 ? fused_launch<0, 16, 8, true, true>(s, cam, rc, accum, counter, knobs, stream, timer)
+                       : fused_launch<0, 16, 8, false, true>(s, cam, rc, accum, counter, knobs, stream, timer);
         return RT_FUSED(0, RT_STACK_DEPTH, 5);
     case 1: return RT_FUSED(1, RT_STACK_DEPTH, 4);
     case 2: return RT_FUSED(2, RT_STACK_DEPTH, 5);

@@ -90,4 +90,5 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
                            RtKernelTimer *timer);
 
 #define RT_WAVEFRONT_BATCH_SPP 8u      // samples per pixel resident in the path queues at once
-#define RT_FUSED_WORKSPACE 4096u
+#define RT_FUSED_HEADER 4096u          // the least workspace the fused kernel runs with
+size_t rt_fused_workspace_bytes();      // what it wants: header + deep-stack columns

@@ -43,7 +43,9 @@ def test_error_paths_without_a_gpu():
     # a null scene is rejected with a message, not a crash
     assert lib.rt_scene_commit(None) < 0
     assert b"null" in lib.rt_last_error()
-    assert lib.rt_render_workspace_size(abi.RT_PIPELINE_FUSED, 1920, 1080) == 4096
+    # header + the deep-stack columns of the largest grid: independent of the image, modest
+    assert 4096 <= lib.rt_render_workspace_size(abi.RT_PIPELINE_FUSED, 1920, 1080) <= 64 << 20
+    assert lib.rt_render_workspace_size(abi.RT_PIPELINE_FUSED, 64, 64) == lib.rt_render_workspace_size(abi.RT_PIPELINE_FUSED, 1920, 1080)
     ws = lib.rt_render_workspace_size(abi.RT_PIPELINE_WAVEFRONT, 1920, 1080)
     assert 1920 * 1080 * 8 * 192 < ws < 1920 * 1080 * 8 * 193
 

@@ -251,6 +251,40 @@ def test_sphere_cloud_bulk_entry_point(ctx):
     assert (g["material_offset"][hit] == r["material_offset"][hit]).all()
 
 
+def test_deep_tree_stack_beyond_its_lds_entries(ctx):
+    """Spheres-only scenes with a tree deeper than 16 run the fused kernel with 16 stack entries
+    per lane in LDS and the rest in global memory.  200k nested spheres make every box contain the
+    centre, so a ray aimed there pushes one entry per level (18 levels) before its first leaf: the
+    image must be the one the wavefront pipeline (whole stack in LDS) gives, and first hits the
+    oracle's."""
+    from raytracer_amd.renderer import NativeScene, Renderer, camera_rays
+    n = 200_000
+    cloud = scenes.SphereCloud(n, 9)
+    rng = np.random.default_rng(9)
+    cloud.centers = (rng.standard_normal((n, 3)) * 0.01).astype(np.float32)
+    cloud.radii = np.linspace(1.0, 60.0, n).astype(np.float32)
+    nat = NativeScene(ctx)
+    cloud.encode(nat)
+    nat.commit()
+    assert nat.stats()["bvh_depth"] > 16
+    a = Renderer(cloud, 192, 108, pipeline=abi.RT_PIPELINE_FUSED, ctx=ctx)
+    b = Renderer(cloud, 192, 108, pipeline=abi.RT_PIPELINE_WAVEFRONT, ctx=ctx)
+    for r in (a, b):
+        r.draw(4, 10, 5)
+    torch.cuda.synchronize()
+    x, y = a.accum, b.accum
+    assert torch.isfinite(x).all() and x.sum().item() > 0
+    close = ((x - y).abs() <= 1e-4 * max(1.0, y.abs().max().item())).float().mean().item()
+    print("pixels equal to 1e-4:", close)
+    assert close > 0.999
+    orc = ob.OracleScene()
+    cloud.encode(orc)
+    orc.commit()
+    rays = camera_rays(ctx, cloud.camera, RenderConfig(1, 1, 1, 3, 0), 64, 36).astype(np.float32)
+    g, r = nat.first_hit(rays), orc.first_hit(rays)
+    assert (g["object"] == r["object"]).mean() > 0.999 and (r["object"] >= 0).sum() > 100
+
+
 def test_full_size_properties_1080p():
     """BASELINE sizes are too large for the oracle; properties that hold at any size:
     linearity in samples (two halves of the sample range add up to the whole, to the
