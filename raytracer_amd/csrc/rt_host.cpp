@@ -1143,7 +1143,8 @@ int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, i
     if (!sc || !cc || !rc || !accum_dev || !workspace_dev || width <= 0 || height <= 0)
         return fail(RT_ERR_INVALID, "bad argument");
     if (!sc->committed) return fail(RT_ERR_STATE, "scene not committed");
-    if ((uint64_t)width * (uint64_t)height > (1u << 28)) return fail(RT_ERR_LIMIT, "image too large");
+    if ((uint64_t)width * (uint64_t)height > (1u << 28) || width > 65535 || height > 65535)     // a lane keeps its pixel as x | y << 16
+        return fail(RT_ERR_LIMIT, "image too large");
     RtDevCamera cam;
     make_camera(*cc, width, height, cam);
     RtDevRender r = make_render(*rc, width, height);

@@ -251,6 +251,14 @@ def test_sphere_cloud_bulk_entry_point(ctx):
     assert (g["material_offset"][hit] == r["material_offset"][hit]).all()
 
 
+def test_image_sides_beyond_16_bits_are_refused(ctx):
+    from raytracer_amd._native import NativeError
+    from raytracer_amd.renderer import Renderer
+    r = Renderer(scenes.simple_balls(), 70000, 1, ctx=ctx)
+    with pytest.raises(NativeError, match="image too large"):
+        r.draw(1, 2, 1)
+
+
 def test_deep_tree_stack_beyond_its_lds_entries(ctx):
     """Spheres-only scenes with a tree deeper than 16 run the fused kernel with 16 stack entries
     per lane in LDS and the rest in global memory.  200k nested spheres make every box contain the

@@ -1,7 +1,7 @@
 """Parity evidence in one file: for every workload, first-hit agreement of the HIP path with the
 double-precision CPU oracle on the workload's own camera rays, and PSNR / RMSE of the mean radiance
 (same seeds on both sides, reduced image size so that the oracle finishes in seconds).
-usage (GPU box): python tools/parity_report.py > gpurun_out/parity_report.json"""
+usage (GPU box): python tools/parity_report.py [workload ...] > gpurun_out/parity_report.json"""
 import json
 import os
 import sys
@@ -19,11 +19,15 @@ from raytracer_amd.scene import RenderConfig  # noqa: E402
 
 ctx = Context(0)
 out = {}
-names = ["cfg1_random_spheres_400x225", "cfg3_cornell_smoke_1080p", "cfg4_csg_textured_1080p", "f2_bouncing_spheres_1080p",
-         "f3_kit_world1_1080p", "f3_kit_world2_1080p"]
+names = sys.argv[1:] or ["cfg1_random_spheres_400x225", "cfg3_cornell_smoke_1080p", "cfg4_csg_textured_1080p",
+                         "cfg5_sphere_cloud_4k", "f2_bouncing_spheres_1080p", "f3_kit_world1_1080p", "f3_kit_world2_1080p"]
 for name in names:
     scene, w, h, _, depth, seed = scenes.make_workload(name)
-    w, h, spp = (w, h, 16) if w <= 480 else (w // 8, h // 8, 16)
+    spp = 16
+    while w > 480:
+        w, h = w // 2, h // 2
+    if w == 480:
+        w, h = 240, 135
     orc = ob.oracle_scene_from(scene)
     entry = {"image": [w, h], "spp": spp, "depth": depth, "seed": seed}
     r = Renderer(scene, w, h, ctx=ctx)
