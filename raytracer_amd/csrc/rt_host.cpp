@@ -5,7 +5,8 @@
 // concrete Swift type it writes structure-of-arrays streams split by what each stage reads
 // (see rt_shared.h).  The BVH follows RayTracingKit/Hittable.swift:609-631: longest axis
 // of the node's box (ties as AABB.swift:59-66), objects ordered by box centre on that
-// axis, split at (n+1)/2 - linearised into 64-byte nodes that carry both child boxes.
+// axis, split at (n+1)/2 (or, by default, a binned surface-area split) - linearised into
+// 64-byte nodes that carry both child boxes, plus a 32-byte half-precision copy of them.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -120,9 +121,6 @@ void xform(const HostShape &s, const float p[3], float out[3]) {
     for (int r = 0; r < 3; r++) out[r] = s.rot[r] * p[0] + s.rot[3 + r] * p[1] + s.rot[6 + r] * p[2] + s.trans[r];
 }
 
-// Bounding boxes: Primitives.swift:29-33 (sphere), :112-125 (cylinder, disk formula),
-// :163-180 (cuboid corners), :253-260 (quad corners); CSG.swift:21-23 (subtract = lhs),
-// :60-66 (union), :102-108 (intersection); ConstantDensityVolume.swift:21-23.
 // ---- where a moving object can be during [0, 1): Transform3D.boundingBoxForAnimation,
 // RayTracingKit/Transform.swift:93-154, in double precision.
 struct Quatd { double w, x, y, z; };
@@ -184,6 +182,9 @@ Box3 sweep_box(const float quat[4], const float trans[3], const Box3 &box) {
     return out;
 }
 
+// Bounding boxes: Primitives.swift:29-33 (sphere), :112-125 (cylinder, disk formula),
+// :163-180 (cuboid corners), :253-260 (quad corners); CSG.swift:21-23 (subtract = lhs),
+// :60-66 (union), :102-108 (intersection); ConstantDensityVolume.swift:21-23.
 Box3 shape_box(const RtScene &sc, int id) {
     const HostShape &s = sc.shapes[id];
     Box3 b;
