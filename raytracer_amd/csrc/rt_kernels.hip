@@ -791,6 +791,7 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     uint32_t tiles_x = (rc.width + 7u) / 8u, tiles_y = (rc.height + 7u) / 8u, n_tiles = tiles_x * tiles_y;
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS, NODE16, DEEP>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
+    if (DEEP) occ = std::min(occ, 8);        // the deep-stack columns are sized for 8 workgroups per CU
     int grid = device_cus() * occ;
     // Work items = tiles x sample chunks.  Large chunks leave the waves finishing at different
     // times at the end of the launch (with 3 chunks per tile that tail was 15 % of a 1024-spp
