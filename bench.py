@@ -33,14 +33,14 @@ make_scene = scenes.make_workload
 
 def cpu_baseline(name):
     """The CPU oracle (double precision restatement of the reference renderer) timed on a
-    bounded sample of the same workload: the same scene at 960x540, 32 spp."""
+    bounded sample of the same workload: the same scene at 960x540, 256 spp (10-25 s on 16 threads)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_bridge as ob
     scene, w, h, spp, depth, seed = make_scene(name)
     if name.startswith("cfg5"):
         return None
     orc = ob.oracle_scene_from(scene)
-    cw, ch, cspp = min(w, 960), min(h, 540), 32        # ~15-25 s of CPU work
+    cw, ch, cspp = min(w, 960), min(h, 540), 256
     threads = min(16, os.cpu_count() or 1)
     orc.render(scene.camera, RenderConfig(1, depth, 1, seed, 0), cw, ch, threads=threads)      # warm
     t0 = time.perf_counter()

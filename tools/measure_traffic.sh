@@ -12,4 +12,5 @@ run fetch "FETCH_SIZE"
 run write "WRITE_SIZE"
 run l2 "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum"
 python3 tools/pmc_summary.py gpurun_out/pmc_fetch_${W}_$TAG gpurun_out/pmc_write_${W}_$TAG gpurun_out/pmc_l2_${W}_$TAG > gpurun_out/traffic_${W}_$TAG.json
-cat gpurun_out/traffic_${W}_$TAG.json
+python3 tools/traffic_json.py $W $SPP gpurun_out/traffic_${W}_$TAG.json > gpurun_out/traffic_record_${W}_$TAG.json
+cat gpurun_out/traffic_record_${W}_$TAG.json
