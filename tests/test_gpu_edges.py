@@ -309,6 +309,12 @@ def test_deep_tree_stack_beyond_its_lds_entries(ctx):
     close = ((x - y).abs() <= 1e-4 * max(1.0, y.abs().max().item())).float().mean().item()
     print("pixels equal to 1e-4:", close)
     assert close > 0.999
+    # a caller that hands over only the 4-KB header gets the kernel with the whole stack in LDS
+    c = Renderer(cloud, 192, 108, pipeline=abi.RT_PIPELINE_FUSED, ctx=ctx)
+    c.workspace = torch.empty(4096, dtype=torch.uint8, device=c.workspace.device)
+    c.draw(4, 10, 5)
+    torch.cuda.synchronize()
+    assert ((c.accum - y).abs() <= 1e-4 * max(1.0, y.abs().max().item())).float().mean().item() > 0.999
     orc = ob.OracleScene()
     cloud.encode(orc)
     orc.commit()
