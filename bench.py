@@ -11,6 +11,7 @@ spp per GPU is fixed) and the per-GPU radiance sums are added with one RCCL all-
 inside the timed region.  Rank 0 prints one JSON line.
 """
 import argparse
+import faulthandler
 import json
 import os
 import sys
@@ -64,6 +65,8 @@ def main():
     ap.add_argument("--node-min", type=int, default=-1)
     ap.add_argument("--nodes", default="auto", choices=["auto", "f32", "f16"])
     args = ap.parse_args()
+    # a run that stops making progress ends with the Python stacks of all threads instead of hanging
+    faulthandler.dump_traceback_later(int(os.environ.get("RT_BENCH_WATCHDOG", "1200")), exit=True)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -71,8 +74,12 @@ def main():
     # RT_DIST_BACKEND=gloo lets the multi-rank path be rehearsed where the ranks share one GPU
     backend = os.environ.get("RT_DIST_BACKEND", "nccl")
     local_rank %= max(1, torch.cuda.device_count())
-    if world > 1:
+    # RT_FORCE_DIST=1 takes the collective path with a single rank too (a check that RCCL initialises
+    # and reduces next to the HIP library on a one-GPU box)
+    use_dist = world > 1 or bool(os.environ.get("RT_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -90,17 +97,29 @@ def main():
                  bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_MEDIAN_SPLIT, refill=args.refill or None, node_min=None if args.node_min < 0 else args.node_min,
                  nodes={"auto": abi.RT_NODES_AUTO, "f32": abi.RT_NODES_F32, "f16": abi.RT_NODES_F16}[args.nodes])
 
+    trace = bool(os.environ.get("RT_BENCH_TRACE"))
+
     def step(i):
         # rank g renders sample indices [ (i*world + g)*spp, +spp ): disjoint over ranks and steps
-        if world > 1:
+        if use_dist:
             r.accum.zero_()      # each step reduces its own sums (a running total would be re-added)
         r.draw(spp, depth, seed, first_sample=(i * world + rank) * spp)
-        if world > 1:
+        if trace:
+            torch.cuda.synchronize()
+            print("rank %d step %d rendered" % (rank, i), file=sys.stderr, flush=True)
+        if use_dist:
+            if backend != "nccl":
+                # gloo stages the tensor through the host from a helper thread; with two ranks
+                # time-sliced on one GPU that wait was seen to stall behind the running kernel
+                torch.cuda.synchronize()
             dist.all_reduce(r.accum, op=dist.ReduceOp.SUM)
+        if trace:
+            torch.cuda.synchronize()
+            print("rank %d step %d reduced" % (rank, i), file=sys.stderr, flush=True)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -114,7 +133,7 @@ def main():
         step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -156,7 +175,8 @@ def main():
             if cb:
                 out["cpu_baseline"] = cb
         print(json.dumps(out))
-    if world > 1:
+    faulthandler.cancel_dump_traceback_later()
+    if use_dist:
         dist.destroy_process_group()
 
 
