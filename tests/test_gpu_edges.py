@@ -324,7 +324,7 @@ def test_deep_tree_stack_beyond_its_lds_entries(ctx):
 
 
 def test_full_size_properties_1080p():
-    """BASELINE sizes are too large for the oracle; properties that hold at any size:
+    """The full benchmark sizes are too large for the oracle; properties that hold at any size:
     linearity in samples (two halves of the sample range add up to the whole, to the
     order of float adds), determinism of the wavefront pipeline, non-negativity."""
     from raytracer_amd.renderer import Renderer
