@@ -5,8 +5,10 @@
  * "Swift scene API -> C structs shared with the kernel -> kernel argument table"
  * (MetalRayTracer/Renderable.h, Materials.h, Config.h; SceneBuffers.swift;
  * ContentView.swift Renderer).  This header is that seam as a C ABI: the records
- * keep the reference's field names, meaning and enum values; simd vector types
- * are spelled as plain float arrays and Metal handles as 32-bit ids.
+ * keep the reference's field names, meaning, enum values AND byte layout (simd
+ * vectors are 16-byte RtFloat3, the Metal resource id an 8-byte word holding a
+ * texture id), so a host that already builds the reference's records passes them
+ * as they are.
  *
  * Conventions
  *  - every function returns >= 0 on success (an id where documented) and a
@@ -31,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 enum {
     RT_OK = 0,
@@ -41,28 +43,38 @@ enum {
     RT_ERR_DEVICE = -4,       /* HIP runtime error */
 };
 
+/* ---- simd types ---------------------------------------------------------------
+ * The reference's records are built from Apple simd types: vector_float3 is 16 bytes
+ * with 16-byte alignment (three floats + one unused), matrix_float3x3 is three such
+ * columns.  The records below have exactly those sizes and field offsets (checked by
+ * static_asserts in rt_host.cpp), so the bytes of a reference `Sphere`, `Cuboid`,
+ * `CameraConfig`, ... can be handed over as they are. */
+#define RT_ALIGN16 __attribute__((aligned(16)))
+typedef struct RT_ALIGN16 { float x, y, z, unused; } RtFloat3;        /* vector_float3 / simd_float3 */
+typedef struct { RtFloat3 columns[3]; } RtMatrix3x3;                   /* matrix_float3x3: column-major */
+
 /* ---- geometry records: MetalRayTracer/Renderable.h:13-63 ------------------- */
 
-/* Renderable.h:13-16.  rotation is column-major (rotation[3*c + r] = columns[c][r]). */
-typedef struct { float rotation[9]; float translation[3]; } RtTransform;
+/* Renderable.h:13-16 (64 bytes). */
+typedef struct { RtMatrix3x3 rotation; RtFloat3 translation; } RtTransform;
 
-/* Renderable.h:18-25 */
+/* Renderable.h:18-25 (80 bytes: radius at 64, material_offset at 72). */
 typedef struct { RtTransform transform; float radius; size_t material_offset; } RtSphere;
 
-/* Renderable.h:27-37: local frame has the axis on +y and the base at the origin. */
+/* Renderable.h:27-37 (96 bytes): local frame has the axis on +y and the base at the origin. */
 typedef struct {
     RtTransform transform;
     float radius, height;
     size_t bottom_material_offset, top_material_offset, side_material_offset;
 } RtCylinder;
 
-/* Renderable.h:39-52: box [0,size] in the local frame. */
+/* Renderable.h:39-52 (128 bytes): box [0,size] in the local frame. */
 enum RtFace { rt_face_left, rt_face_right, rt_face_bottom, rt_face_top, rt_face_back, rt_face_front };
-typedef struct { RtTransform transform; float size[3]; size_t material_offset[6]; } RtCuboid;
+typedef struct { RtTransform transform; RtFloat3 size; size_t material_offset[6]; } RtCuboid;
 
-/* Renderable.h:54-63: w = n/|n|^2, normal = n/|n|, d = dot(origin, normal), n = cross(u, v)
- * (Primitives.swift:266-274). */
-typedef struct { float origin[3], u[3], v[3], w[3], normal[3]; float d; size_t material_offset; } RtQuad;
+/* Renderable.h:54-63 (96 bytes): w = n/|n|^2, normal = n/|n|, d = dot(origin, normal),
+ * n = cross(u, v) (Primitives.swift:266-274). */
+typedef struct { RtFloat3 origin, u, v, w, normal; float d; size_t material_offset; } RtQuad;
 
 /* ---- material records: MetalRayTracer/Materials.h:16-93 -------------------- */
 
@@ -81,53 +93,55 @@ enum RtMaterialKind {
     rt_material_kind_emissive_kit_texture,
 };
 
-/* Materials.h:30-36: the Metal resource id becomes the id rt_add_texture_rgb8 returned. */
-typedef struct { uint32_t texture_id; } RtImageTexture;
+typedef RtFloat3 RtSolidColor;                                         /* Materials.h:28 */
 
-/* Materials.h:38-45 */
+/* Materials.h:30-36: the 8-byte MTLResourceID holds the id rt_add_texture_rgb8 returned. */
+typedef struct { uint64_t texture_ptr; } RtImageTexture;
+
+/* Materials.h:38-45 (4912 bytes: vectors at 48, permutations at 4144). */
 #define RT_PERLIN_TABLE_SIZE 256
 typedef struct {
-    float colors[2][3];
+    RtSolidColor colors[2];
     float frequency;
     uint32_t turbulence;
-    float vectors[RT_PERLIN_TABLE_SIZE][3];
+    RtFloat3 vectors[RT_PERLIN_TABLE_SIZE];
     uint8_t permutations[3][RT_PERLIN_TABLE_SIZE];
 } RtPerlinNoiseTexture;
 
-/* Materials.h:47-93.  The first 4 bytes of every record are its kind. */
-typedef struct { uint32_t kind; float albedo[3]; } RtColoredLambertianMaterial;
+/* Materials.h:47-93.  The first 4 bytes of every record are its kind; sizes 32, 16, 4928,
+ * 48, 24, 4944, 8, 32, 32 bytes. */
+typedef struct { uint32_t kind; RtSolidColor albedo; } RtColoredLambertianMaterial;
 typedef struct { uint32_t kind; RtImageTexture albedo; } RtTexturedLambertianMaterial;
 typedef struct { uint32_t kind; RtPerlinNoiseTexture albedo; } RtPerlinNoiseLambertianMaterial;
-typedef struct { uint32_t kind; float albedo[3]; float fuzz; } RtColoredMetalMaterial;
+typedef struct { uint32_t kind; RtSolidColor albedo; float fuzz; } RtColoredMetalMaterial;
 typedef struct { uint32_t kind; RtImageTexture albedo; float fuzz; } RtTexturedMetalMaterial;
 typedef struct { uint32_t kind; RtPerlinNoiseTexture albedo; float fuzz; } RtPerlinNoiseMetalMaterial;
 typedef struct { uint32_t kind; float refraction_index; } RtDielectricMaterial;
-typedef struct { uint32_t kind; float albedo[3]; } RtColoredEmissiveMaterial;
-typedef struct { uint32_t kind; float albedo[3]; } RtColoredIsotropicMaterial;
+typedef struct { uint32_t kind; RtSolidColor albedo; } RtColoredEmissiveMaterial;
+typedef struct { uint32_t kind; RtSolidColor albedo; } RtColoredIsotropicMaterial;
 
 /* ---- configuration: MetalRayTracer/Config.h:13-33 -------------------------- */
 
 enum RtBackgroundLighting { rt_background_lighting_none, rt_background_lighting_sky };
 
-/* Config.h:18-26 */
+/* Config.h:18-26 (80 bytes: look_from at 16, look_at 32, up 48, defocus_angle 64,
+ * focus_distance 68, background 72). */
 typedef struct {
     float vertical_FOV;
-    float look_from[3], look_at[3], up[3];
+    RtFloat3 look_from, look_at, up;
     float defocus_angle;
     float focus_distance;
     uint32_t background;
 } RtCameraConfig;
 
-/* Config.h:28-33.  samples_per_pixel more samples are ADDED to the accumulator by one
- * rt_render call.  pass_counter keeps the reference's meaning (number of the pass, 1
- * based) and, because each pass here may hold many samples, first_sample gives the
- * global index of the call's first sample: sample s of pixel (x, y) always uses the same
- * random stream, whichever call, pipeline or GPU renders it. */
+/* Config.h:28-33 (24 bytes: rng_seed at 16).  samples_per_pixel more samples are ADDED to
+ * the accumulator by one rt_render call; pass_counter keeps the reference's meaning (number
+ * of the pass, 1 based).  Which samples a call renders is the `first_sample` argument of
+ * rt_render, not a field: this record is the reference's, byte for byte. */
 typedef struct {
     uint32_t samples_per_pixel;
     uint32_t max_depth;
     uint32_t pass_counter;
-    uint32_t first_sample;
     uint64_t rng_seed;
 } RtRenderConfig;
 
@@ -268,7 +282,7 @@ int rt_add_sphere_objects(RtScene *, int n, const float *center_radius, const ui
 int rt_scene_commit(RtScene *);
 int rt_scene_stats(const RtScene *, RtSceneStats *out);
 
-/* Tuning knobs; no counterpart in the reference (Metal's acceleration structure is opaque).
+/* Options; no counterpart in the reference (Metal's acceleration structure is opaque).
  * RT_OPTION_BVH_BUILDER (before commit): RT_BVH_MEDIAN_SPLIT is the reference's rule
  * (RayTracingKit/Hittable.swift:609-631), RT_BVH_SAH (default) a binned surface-area
  * heuristic; hit results do not depend on the choice.  RT_OPTION_REFILL_THRESHOLD: how many
@@ -277,10 +291,23 @@ int rt_scene_stats(const RtScene *, RtSceneStats *out);
  * RT_OPTION_NODE_FORMAT (before commit): how rt_render's fused kernel reads BVH nodes.
  * RT_NODES_F16 stores the child boxes as halves rounded outward (32-byte nodes, half the
  * fetch work; boxes only cull, so hits are the same), RT_NODES_F32 keeps the 64-byte nodes,
- * RT_NODES_AUTO (default) takes halves unless a box plane lies beyond +-60000. */
-enum RtOption { RT_OPTION_BVH_BUILDER = 1, RT_OPTION_REFILL_THRESHOLD = 2, RT_OPTION_NODE_MIN = 3, RT_OPTION_NODE_FORMAT = 4 };
+ * RT_NODES_AUTO (default) takes halves unless a box plane lies beyond +-60000.
+ * RT_OPTION_KERNEL_TIMING: 1 records HIP events around every launch of the render loop's
+ * dominant kernel for rt_kernel_time (off by default: a viewer that never asks pays nothing).
+ * RT_OPTION_PROFILE_PHASES: 1 runs the diagnostic build of the fused kernel that counts
+ * per-phase executions, lanes and cycles into the workspace header.
+ * RT_OPTION_CONVENTION (before commit): where the reference's two renderers disagree,
+ * RT_CONVENTION_METAL (default) follows MetalRayTracer (sphere / tube u of
+ * Impl/RenderableImpl.h:83,205, cap uv of :113-121, metal scatter of MaterialsImpl.h:163-171),
+ * RT_CONVENTION_KIT follows RayTracingKit (sphere u of Hittable.swift:188, cap and tube uv of
+ * :245-248,281-282, metal scatter of Material.swift:53-57: absorb on <= 0). */
+enum RtOption {
+    RT_OPTION_BVH_BUILDER = 1, RT_OPTION_REFILL_THRESHOLD = 2, RT_OPTION_NODE_MIN = 3, RT_OPTION_NODE_FORMAT = 4,
+    RT_OPTION_KERNEL_TIMING = 5, RT_OPTION_PROFILE_PHASES = 6, RT_OPTION_CONVENTION = 7
+};
 enum RtBvhBuilder { RT_BVH_MEDIAN_SPLIT = 0, RT_BVH_SAH = 1 };
 enum RtNodeFormat { RT_NODES_AUTO = 0, RT_NODES_F32 = 1, RT_NODES_F16 = 2 };
+enum RtConvention { RT_CONVENTION_METAL = 0, RT_CONVENTION_KIT = 1 };
 int rt_scene_set_option(RtScene *, int option, int value);
 
 /* ---- queries (parity surface) ------------------------------------------------ */
@@ -302,9 +329,18 @@ int rt_intervals(RtScene *, int shape, const float *rays_dev, int n,
 /* The ray-generation stage alone (Shaders.metal:30-67): rays of samples
  * first_sample .. first_sample+samples_per_pixel-1 of the pixels of the window
  * [x0,x0+w) x [y0,y0+h), pixel-major then sample; out n x 6 floats. */
-int rt_camera_rays(RtContext *, const RtCameraConfig *, const RtRenderConfig *,
+int rt_camera_rays(RtContext *, const RtCameraConfig *, const RtRenderConfig *, uint32_t first_sample,
                    int width, int height, int x0, int y0, int w, int h,
                    float *rays_out_dev, void *stream);
+
+/* Raw words of the device generators (Impl/RNG.h:31-52 PCG32; RayTracingKit/PRNG.swift:17-21
+ * WyRand) for bit-exact comparison with a host implementation.  streams_dev holds n records
+ * of 8 uint32 words: rng_seed low word, rng_seed high word, sample, x, y, 0, 0, 0.  For
+ * record i the first words_per_stream PCG32 outputs of the stream of that (pixel, sample) go
+ * to out_dev[i * words_per_stream ...], and the 64-bit WyRand output number `sample` of
+ * rng_seed (the per-sample seed) to wyrand_out_dev[2 i] (low word), [2 i + 1] (high word). */
+int rt_rng_words(RtContext *, const uint32_t *streams_dev, int n, int words_per_stream,
+                 uint32_t *out_dev, uint32_t *wyrand_out_dev, void *stream);
 
 /* ---- render: replaces Renderer.draw (ContentView.swift:182-224) --------------- */
 
@@ -314,10 +350,26 @@ size_t rt_render_workspace_size(int pipeline, int width, int height);
 /* Adds config->samples_per_pixel samples per pixel to accum_dev: width*height*3 floats,
  * the per-pixel RGB radiance SUMS (row-major, interleaved RGB).  The caller keeps the
  * sample count (the reference keeps passCounter on the host too, ContentView.swift:187).
+ * first_sample is the global index of the call's first sample: sample s of pixel (x, y)
+ * always uses the same random stream, whichever call, pipeline or GPU renders it (the
+ * reference draws a fresh rng_seed per pass instead; a caller that does so passes 0).
  * workspace_dev must hold rt_render_workspace_size bytes. */
-int rt_render(RtScene *, const RtCameraConfig *, const RtRenderConfig *, int pipeline,
+int rt_render(RtScene *, const RtCameraConfig *, const RtRenderConfig *, uint32_t first_sample, int pipeline,
               int width, int height, float *accum_dev,
               void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* Image-space sharding for several GPUs; no counterpart in the reference (one device).
+ * The image is cut into bands of 8 pixel rows; band b belongs to shard b % band_count.
+ * This call renders the bands of shard band_index only (fused pipeline) and adds them to
+ * accum_bands_dev, which holds just those bands stacked in order:
+ * rt_band_rows(height, band_index, band_count) rows of width*3 floats.  Random streams are
+ * those of the full image, so the shards of all ranks put together are the image rt_render
+ * gives.  Equal-sized shard buffers (rt_band_rows(height, 0, band_count) rows) gathered
+ * from all ranks hold every pixel exactly once: no arithmetic in the exchange. */
+int rt_band_rows(int height, int band_index, int band_count);
+int rt_render_bands(RtScene *, const RtCameraConfig *, const RtRenderConfig *, uint32_t first_sample,
+                    int band_index, int band_count, int width, int height, float *accum_bands_dev,
+                    void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* Camera.swift:92 / Vector3D.swift:181-211: mean -> min(sqrt(x), 1) ->
  * floor(255.999.. * x), written as RGBX8 (width*height*4 bytes); n_samples is the number
@@ -335,8 +387,9 @@ int rt_resolve_rgb8(RtContext *, const float *accum_dev, uint32_t n_samples, int
 int rt_progressive_present(RtContext *, const float *pass_sum_dev, uint32_t samples_per_pixel, uint32_t pass_counter,
                            uint32_t *acc_rgb10a2_dev, uint8_t *bgra8_out_dev, int width, int height, void *stream);
 
-/* Timing of the render loop's dominant kernel on its own stream (HIP events around
- * every launch since the last reset): total milliseconds and launch count. */
+/* Timing of the render loop's dominant kernel on its own stream, when RT_OPTION_KERNEL_TIMING
+ * is on (HIP events around every launch since the last reset): total milliseconds and
+ * launch count. */
 int rt_kernel_time(RtScene *, int reset, double *total_ms, uint64_t *launches, const char **kernel_name);
 
 #ifdef __cplusplus

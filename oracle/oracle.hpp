@@ -186,6 +186,9 @@ struct Shape {
     double density = 0;
     // motion blur (RayTracingKit/Hittable.swift:528-555): `base` moved by transform.pow(time)
     double m_quat[4] = {1, 0, 0, 0}, m_trans[3] = {0, 0, 0};     // w, x, y, z
+    // texture coordinates of RayTracingKit (Hittable.swift:188,245-248,281-282) instead of the
+    // Metal side's (RenderableImpl.h:83,113-121,205); copied from the scene when the shape is added
+    bool kit_uv = false;
     Box box;
 };
 
@@ -209,6 +212,7 @@ struct Counters {
 
 struct Scene {
     bool animated = false;      // some shape is a MOTION: camera samples draw a time
+    bool kit_convention = false;   // RayTracingKit's texture coordinates and metal rule (Material.swift:53-57)
     std::vector<Shape> shapes;
     std::vector<int> objects;
     std::vector<OrcMaterial> materials;
@@ -248,8 +252,8 @@ template <class R> struct Enum {
 
 // RenderableImpl.h:30-87
 template <class R> struct SphereEnum final : Enum<R> {
-    Xf<R> xf; R radius; uint64_t mat; Ray<R> ray; R ts[2]; int index;
-    SphereEnum(const Shape &s, Ray<R> r) : xf(xf_of<R>(s)), radius(R(s.radius)), mat(s.mat[0]), ray(r) {
+    Xf<R> xf; R radius; uint64_t mat; Ray<R> ray; R ts[2]; int index; bool kit_uv;
+    SphereEnum(const Shape &s, Ray<R> r) : xf(xf_of<R>(s)), radius(R(s.radius)), mat(s.mat[0]), ray(r), kit_uv(s.kit_uv) {
         V3<R> oc = ray.origin - xf.t;
         R a = dot(ray.direction, ray.direction);
         R b_2 = dot(ray.direction, oc);
@@ -273,7 +277,8 @@ template <class R> struct SphereEnum final : Enum<R> {
     uint64_t material_offset() const override { return mat; }
     void texture_coordinates(R &u, R &v) const override {
         V3<R> n = xf.rot_t(normal());
-        u = (std::atan2(n.z, -n.x) + kPi<R>()) / (2 * kPi<R>());
+        if (kit_uv) u = (std::atan2(-n.z, n.x) + kPi<R>()) / (2 * kPi<R>());      // Hittable.swift:188
+        else u = (std::atan2(n.z, -n.x) + kPi<R>()) / (2 * kPi<R>());             // RenderableImpl.h:83
         v = std::acos(-n.y) / kPi<R>();
     }
 };
@@ -287,15 +292,22 @@ template <class R> struct PlainHit { R t = 0; V3<R> normal; uint64_t mat = 0; R 
 template <class R> struct CylinderEnum final : Enum<R> {
     Ray<R> ray; PlainHit<R> hit[2]; int index;
 
-    static void plane_uv(V3<R> lp, R radius, R flipX, R &u, R &v) {          // :141-146
-        u = R(0.5) + lp.z * flipX / (2 * radius);
-        v = R(0.5) + lp.x / (2 * radius);
+    bool kit_uv;
+    void plane_uv(V3<R> lp, R radius, R flipX, R &u, R &v) const {
+        if (kit_uv) {                                                         // Hittable.swift:245,248
+            u = R(0.5) + lp.x / (2 * radius);
+            v = R(0.5) + lp.z / (2 * radius);
+        } else {                                                              // RenderableImpl.h:141-146
+            u = R(0.5) + lp.z * flipX / (2 * radius);
+            v = R(0.5) + lp.x / (2 * radius);
+        }
     }
-    static void tube_uv(V3<R> lp, R height, R &u, R &v) {                     // :203-208
-        u = (std::atan2(lp.z, -lp.x) + kPi<R>()) / (2 * kPi<R>());
+    void tube_uv(V3<R> lp, R height, R &u, R &v) const {
+        if (kit_uv) u = std::atan2(lp.z, lp.x) / (2 * kPi<R>());              // Hittable.swift:281
+        else u = (std::atan2(lp.z, -lp.x) + kPi<R>()) / (2 * kPi<R>());       // RenderableImpl.h:203-208
         v = lp.y / height;
     }
-    CylinderEnum(const Shape &s, Ray<R> r) : ray(r) {
+    CylinderEnum(const Shape &s, Ray<R> r) : ray(r), kit_uv(s.kit_uv) {
         Xf<R> xf = xf_of<R>(s);
         R radius = R(s.radius), height = R(s.height);
         Ray<R> lr = inverse_transform(ray, xf);
@@ -1027,10 +1039,10 @@ template <class R> V3<R> material_color(const Scene &sc, const OrcMaterial &m, c
 
 template <class R> struct ScatterResult { V3<R> emitted, attenuation; Ray<R> scattered; };
 
-// MaterialsImpl.h:147-215.  Choices where the two reference renderers differ: metal
-// absorbs when the fuzzed reflection points strictly below the surface (< 0,
-// MaterialsImpl.h:167; Material.swift:55 uses <= 0) and the scattered direction is
-// normalised (MaterialsImpl.h:169).
+// MaterialsImpl.h:147-215.  Where the two reference renderers differ: metal absorbs when the
+// fuzzed reflection points strictly below the surface (< 0, MaterialsImpl.h:167) or, under the
+// Kit convention, on it too (<= 0, Material.swift:55); the scattered direction is normalised
+// either way (MaterialsImpl.h:169; every Kit shape is invariant to the direction's length).
 template <class R> bool scatter(const Scene &sc, const OrcMaterial &m, Ray<R> ray, const HitInfo<R> &hit, Rng &rng, ScatterResult<R> &res) {
     res.emitted = V3<R>();
     res.attenuation = V3<R>();
@@ -1053,7 +1065,8 @@ template <class R> bool scatter(const Scene &sc, const OrcMaterial &m, Ray<R> ra
     case orc_material_kind_metal_textured:
     case orc_material_kind_metal_perlin_noise: {
         V3<R> reflected = reflect(ray.direction, hit.normal) + R(m.fuzz) * random_unit_vector_3d<R>(rng);
-        if (dot(reflected, hit.normal) < 0) return false;
+        const R side = dot(reflected, hit.normal);
+        if (sc.kit_convention ? side <= 0 : side < 0) return false;
         res.attenuation = material_color(sc, m, hit);
         res.scattered = {hit.point, normalize(reflected)};
         return true;

@@ -156,6 +156,8 @@ int orc_kit_texture_color(const OrcScene *, int texture, int precision, double u
 int orc_add_perlin(OrcScene *, const OrcPerlin *);
 
 int orc_shape_sphere(OrcScene *, const OrcSphere *);     /* -> shape id */
+/* n plain spheres added as objects in one call (center_radius: n x 4 floats); -> first object index. */
+int orc_add_sphere_objects(OrcScene *, int n, const float *center_radius, const uint32_t *material_offsets);
 int orc_shape_cylinder(OrcScene *, const OrcCylinder *);
 int orc_shape_cuboid(OrcScene *, const OrcCuboid *);
 int orc_shape_quad(OrcScene *, const OrcQuad *);
@@ -166,6 +168,9 @@ int orc_shape_cdv(OrcScene *, int base, float density);
 int orc_shape_motion(OrcScene *, int base, const double quat_wxyz[4], const double translation[3]);
 /* Time used by orc_enumerate / orc_first_hit (orc_render draws one per sample). */
 void orc_set_query_time(OrcScene *, double time);
+/* 0 (default): texture coordinates and metal rule of MetalRayTracer; 1: RayTracingKit's
+ * (Hittable.swift:188,245-248,281-282; Material.swift:53-57). */
+void orc_set_convention(OrcScene *, int kit);
 /* Bounding box of a shape as the BVH uses it (Hittable.boundingBox): min xyz, max xyz. */
 int orc_shape_bounds(OrcScene *, int shape, double out_min_max[6]);
 /* Transform3D.boundingBoxForAnimation of a point and Transform3D.pow(t).transform(p)
@@ -201,6 +206,8 @@ int orc_render(const OrcScene *, const OrcCameraConfig *, const OrcRenderConfig 
 /* PCG32 (RNG.h:31-52) and WyRand (PRNG.swift:10-22) raw streams. */
 void orc_pcg32(uint64_t initstate, uint64_t initseq, int n, uint32_t *out);
 void orc_wyrand(uint64_t seed, int n, uint64_t *out);
+/* First n PCG32 words of the stream of one (pixel, sample). */
+void orc_sample_stream_words(uint64_t rng_seed, uint32_t sample, uint32_t x, uint32_t y, int n, uint32_t *out);
 /* Seeding of the per-(pixel, sample) stream; returns state and inc. */
 void orc_sample_stream(uint64_t rng_seed, uint32_t sample, uint32_t x, uint32_t y, uint64_t out_state_inc[2]);
 
@@ -210,6 +217,10 @@ void orc_sample_stream(uint64_t rng_seed, uint32_t sample, uint32_t x, uint32_t 
  * drawable's bgra8Unorm pixel (round to nearest even).  pass_sum: n_pixels*3 radiance sums. */
 void orc_progressive_present(const float *pass_sum, uint32_t samples_per_pixel, uint32_t pass_counter,
                              uint32_t *acc, uint8_t *bgra, int n_pixels);
+
+/* Output stage of the CLI renderer (Camera.swift:92, Vector3D.swift:185-191,208-211) in float:
+ * mean, square root, clamp, floor(nextDown(256) * x) -> RGBX8.  sums: n_pixels*3 radiance sums. */
+void orc_resolve_rgb8(const float *sums, uint32_t n_samples, int n_pixels, uint8_t *rgbx);
 
 const char *orc_last_error(void);
 

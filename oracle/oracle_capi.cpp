@@ -64,6 +64,7 @@ static void set_xf(Shape &sh, const OrcTransform &t) {
 }
 static int push(OrcScene *s, Shape &&sh) {
     s->s.committed = false;
+    sh.kit_uv = s->s.kit_convention;
     s->s.shapes.push_back(std::move(sh));
     return (int)s->s.shapes.size() - 1;
 }
@@ -71,6 +72,19 @@ static int push(OrcScene *s, Shape &&sh) {
 int orc_shape_sphere(OrcScene *s, const OrcSphere *p) {
     Shape sh; sh.kind = SPHERE; set_xf(sh, p->transform); sh.radius = p->radius; sh.mat[0] = p->material_offset;
     return push(s, std::move(sh));
+}
+// n plain spheres (identity rotation) as objects in one call: center_radius n x 4 floats.
+int orc_add_sphere_objects(OrcScene *s, int n, const float *center_radius, const uint32_t *material_offsets) {
+    int first = (int)s->s.objects.size();
+    s->s.shapes.reserve(s->s.shapes.size() + (size_t)n);
+    for (int i = 0; i < n; i++) {
+        Shape sh; sh.kind = SPHERE;
+        for (int a = 0; a < 3; a++) sh.trans[a] = center_radius[4 * (size_t)i + a];
+        sh.radius = center_radius[4 * (size_t)i + 3];
+        sh.mat[0] = material_offsets[i];
+        s->s.objects.push_back(push(s, std::move(sh)));
+    }
+    return first;
 }
 int orc_shape_cylinder(OrcScene *s, const OrcCylinder *p) {
     Shape sh; sh.kind = CYLINDER; set_xf(sh, p->transform); sh.radius = p->radius; sh.height = p->height;
@@ -119,6 +133,10 @@ int orc_shape_motion(OrcScene *s, int base, const double quat_wxyz[4], const dou
     return push(s, std::move(sh));
 }
 void orc_set_query_time(OrcScene *s, double time) { s->query_time = time; }
+void orc_set_convention(OrcScene *s, int kit) {
+    s->s.kit_convention = kit != 0;
+    for (Shape &sh : s->s.shapes) sh.kit_uv = kit != 0;
+}
 int orc_shape_bounds(OrcScene *s, int shape, double out_min_max[6]) {
     if (shape < 0 || shape >= (int)s->s.shapes.size()) return fail("bad shape id");
     Box b = shape_box(s->s, shape);
@@ -295,12 +313,31 @@ void orc_pcg32(uint64_t initstate, uint64_t initseq, int n, uint32_t *out) {
 void orc_wyrand(uint64_t seed, int n, uint64_t *out) {
     for (int i = 0; i < n; i++) out[i] = wyrand_at(seed, (uint64_t)i);
 }
+void orc_sample_stream_words(uint64_t rng_seed, uint32_t sample, uint32_t x, uint32_t y, int n, uint32_t *out) {
+    Pcg32 g = sample_stream(rng_seed, sample, x, y);
+    for (int i = 0; i < n; i++) out[i] = g.next_u32();
+}
 void orc_sample_stream(uint64_t rng_seed, uint32_t sample, uint32_t x, uint32_t y, uint64_t out_state_inc[2]) {
     Pcg32 g = sample_stream(rng_seed, sample, x, y);
     out_state_inc[0] = g.state;
     out_state_inc[1] = g.inc;
 }
 
+
+// Camera.swift:92 + Vector3D.swift:185-191,208-211 in float, one operation at a time: sum / n,
+// square root, min with 1, floor(nextDown(256) * x); written as RGBX8.
+void orc_resolve_rgb8(const float *sums, uint32_t n_samples, int n_pixels, uint8_t *rgbx) {
+    const float scale = std::nextafter(256.0f, 0.0f);
+    for (int i = 0; i < n_pixels; i++) {
+        for (int c = 0; c < 3; c++) {
+            float mean = sums[3 * (size_t)i + c] / (float)n_samples;
+            float v = mean > 0.0f ? std::fmin(std::sqrt(mean), 1.0f) : 0.0f;
+            float q = std::floor(scale * v);
+            rgbx[4 * (size_t)i + c] = (uint8_t)(q > 255.0f ? 255.0f : q);
+        }
+        rgbx[4 * (size_t)i + 3] = 0;
+    }
+}
 
 // Shaders.metal:151-158, one float operation at a time (this file is built with
 // -ffp-contract=off, so nothing fuses).

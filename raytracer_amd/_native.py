@@ -16,8 +16,9 @@ EXPORTS = [
     "rt_shape_sphere", "rt_shape_cylinder", "rt_shape_cuboid", "rt_shape_quad", "rt_shape_csg", "rt_shape_cdv",
     "rt_shape_motion", "rt_shape_bounds", "rt_scene_set_time",
     "rt_add_object", "rt_add_sphere_objects", "rt_scene_commit", "rt_scene_stats", "rt_scene_set_option",
-    "rt_first_hit", "rt_intervals", "rt_camera_rays",
-    "rt_render_workspace_size", "rt_render", "rt_resolve_rgb8", "rt_progressive_present", "rt_kernel_time",
+    "rt_first_hit", "rt_intervals", "rt_camera_rays", "rt_rng_words",
+    "rt_render_workspace_size", "rt_render", "rt_band_rows", "rt_render_bands", "rt_resolve_rgb8", "rt_progressive_present",
+    "rt_kernel_time",
 ]
 
 
@@ -62,11 +63,15 @@ def _load():
         "rt_scene_set_option": (i32, [vp, i32, i32]),
         "rt_first_hit": (i32, [vp, vp, i32, f32, f32, u64, vp, vp]),
         "rt_intervals": (i32, [vp, i32, vp, i32, vp, i32, u64, vp, vp, vp]),
-        "rt_camera_rays": (i32, [vp, C.POINTER(abi.RtCameraConfig), C.POINTER(abi.RtRenderConfig), i32, i32, i32, i32,
+        "rt_camera_rays": (i32, [vp, C.POINTER(abi.RtCameraConfig), C.POINTER(abi.RtRenderConfig), u32, i32, i32, i32, i32,
                                  i32, i32, vp, vp]),
+        "rt_rng_words": (i32, [vp, vp, i32, i32, vp, vp, vp]),
         "rt_render_workspace_size": (C.c_size_t, [i32, i32, i32]),
-        "rt_render": (i32, [vp, C.POINTER(abi.RtCameraConfig), C.POINTER(abi.RtRenderConfig), i32, i32, i32, vp, vp,
+        "rt_render": (i32, [vp, C.POINTER(abi.RtCameraConfig), C.POINTER(abi.RtRenderConfig), u32, i32, i32, i32, vp, vp,
                             C.c_size_t, vp]),
+        "rt_band_rows": (i32, [i32, i32, i32]),
+        "rt_render_bands": (i32, [vp, C.POINTER(abi.RtCameraConfig), C.POINTER(abi.RtRenderConfig), u32, i32, i32, i32, i32,
+                                  vp, vp, C.c_size_t, vp]),
         "rt_resolve_rgb8": (i32, [vp, vp, u32, i32, i32, vp, vp]),
         "rt_progressive_present": (i32, [vp, vp, u32, u32, vp, vp, i32, i32, vp]),
         "rt_kernel_time": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(C.c_char_p)]),
@@ -74,8 +79,8 @@ def _load():
     for name in EXPORTS:
         fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
         fn.restype, fn.argtypes = sig[name]
-    if L.rt_abi_version() != 1:
-        raise ImportError("libraytracer_amd.so has ABI version %d, expected 1" % L.rt_abi_version())
+    if L.rt_abi_version() != 2:
+        raise ImportError("libraytracer_amd.so has ABI version %d, expected 2" % L.rt_abi_version())
     return L
 
 

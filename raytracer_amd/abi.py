@@ -29,95 +29,147 @@ material_kind_isotropic_colored = 9
 background_lighting_none = 0
 background_lighting_sky = 1
 
-F3 = C.c_float * 3
+RT_OPTION_KERNEL_TIMING, RT_OPTION_PROFILE_PHASES, RT_OPTION_CONVENTION = 5, 6, 7
+RT_CONVENTION_METAL, RT_CONVENTION_KIT = 0, 1
 
 
-class RtTransform(C.Structure):
-    _fields_ = [("rotation", C.c_float * 9), ("translation", F3)]
+class _Record(C.Structure):
+    """Structure whose positional constructor skips the padding fields (named _pad*), so a
+    record is built from its meaningful fields in header order."""
+
+    def __init__(self, *args, **kw):
+        super().__init__()
+        names = [f[0] for f in self._fields_ if not f[0].startswith("_pad")]
+        if len(args) > len(names):
+            raise TypeError("too many initialisers for %s" % type(self).__name__)
+        for name, value in zip(names, args):
+            setattr(self, name, value)
+        for name, value in kw.items():
+            setattr(self, name, value)
 
 
-class RtSphere(C.Structure):
-    _fields_ = [("transform", RtTransform), ("radius", C.c_float), ("material_offset", C.c_size_t)]
+class RtFloat3(C.Structure):
+    """vector_float3: three floats in 16 bytes."""
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("unused", C.c_float)]
+
+    def __init__(self, x=0.0, y=0.0, z=0.0):
+        super().__init__(x, y, z, 0.0)
+
+    def __iter__(self):
+        return iter((self.x, self.y, self.z))
+
+    def __getitem__(self, i):
+        return (self.x, self.y, self.z)[i]
 
 
-class RtCylinder(C.Structure):
+F3 = RtFloat3
+
+
+class RtMatrix3x3(C.Structure):
+    _fields_ = [("columns", RtFloat3 * 3)]
+
+
+class RtTransform(_Record):
+    _fields_ = [("rotation", RtMatrix3x3), ("translation", F3)]
+
+
+class RtSphere(_Record):
+    _fields_ = [("transform", RtTransform), ("radius", C.c_float), ("_pad0", C.c_uint32), ("material_offset", C.c_size_t)]
+
+
+class RtCylinder(_Record):
     _fields_ = [("transform", RtTransform), ("radius", C.c_float), ("height", C.c_float),
                 ("bottom_material_offset", C.c_size_t), ("top_material_offset", C.c_size_t),
                 ("side_material_offset", C.c_size_t)]
 
 
-class RtCuboid(C.Structure):
+class RtCuboid(_Record):
     _fields_ = [("transform", RtTransform), ("size", F3), ("material_offset", C.c_size_t * 6)]
 
 
-class RtQuad(C.Structure):
+class RtQuad(_Record):
     _fields_ = [("origin", F3), ("u", F3), ("v", F3), ("w", F3), ("normal", F3),
-                ("d", C.c_float), ("material_offset", C.c_size_t)]
+                ("d", C.c_float), ("_pad0", C.c_uint32), ("material_offset", C.c_size_t)]
 
 
-class RtImageTexture(C.Structure):
-    _fields_ = [("texture_id", C.c_uint32)]
+class RtImageTexture(_Record):
+    _fields_ = [("texture_ptr", C.c_uint64)]
 
 
-class RtPerlinNoiseTexture(C.Structure):
-    _fields_ = [("colors", F3 * 2), ("frequency", C.c_float), ("turbulence", C.c_uint32),
+class RtPerlinNoiseTexture(_Record):
+    _fields_ = [("colors", F3 * 2), ("frequency", C.c_float), ("turbulence", C.c_uint32), ("_pad0", C.c_uint32 * 2),
                 ("vectors", F3 * RT_PERLIN_TABLE_SIZE),
                 ("permutations", (C.c_uint8 * RT_PERLIN_TABLE_SIZE) * 3)]
 
 
-class RtColoredLambertianMaterial(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("albedo", F3)]
+class RtColoredLambertianMaterial(_Record):
+    _fields_ = [("kind", C.c_uint32), ("_pad0", C.c_uint32 * 3), ("albedo", F3)]
 
 
-class RtTexturedLambertianMaterial(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("albedo", RtImageTexture)]
+class RtTexturedLambertianMaterial(_Record):
+    _fields_ = [("kind", C.c_uint32), ("_pad0", C.c_uint32), ("albedo", RtImageTexture)]
 
 
-class RtPerlinNoiseLambertianMaterial(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("albedo", RtPerlinNoiseTexture)]
+class RtPerlinNoiseLambertianMaterial(_Record):
+    _fields_ = [("kind", C.c_uint32), ("_pad0", C.c_uint32 * 3), ("albedo", RtPerlinNoiseTexture)]
 
 
-class RtColoredMetalMaterial(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("albedo", F3), ("fuzz", C.c_float)]
+class RtColoredMetalMaterial(_Record):
+    _fields_ = [("kind", C.c_uint32), ("_pad0", C.c_uint32 * 3), ("albedo", F3), ("fuzz", C.c_float), ("_pad1", C.c_uint32 * 3)]
 
 
-class RtTexturedMetalMaterial(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("albedo", RtImageTexture), ("fuzz", C.c_float)]
+class RtTexturedMetalMaterial(_Record):
+    _fields_ = [("kind", C.c_uint32), ("_pad0", C.c_uint32), ("albedo", RtImageTexture), ("fuzz", C.c_float), ("_pad1", C.c_uint32)]
 
 
-class RtPerlinNoiseMetalMaterial(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("albedo", RtPerlinNoiseTexture), ("fuzz", C.c_float)]
+class RtPerlinNoiseMetalMaterial(_Record):
+    _fields_ = [("kind", C.c_uint32), ("_pad0", C.c_uint32 * 3), ("albedo", RtPerlinNoiseTexture), ("fuzz", C.c_float),
+                ("_pad1", C.c_uint32 * 3)]
 
 
-class RtDielectricMaterial(C.Structure):
+class RtDielectricMaterial(_Record):
     _fields_ = [("kind", C.c_uint32), ("refraction_index", C.c_float)]
 
 
-class RtColoredEmissiveMaterial(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("albedo", F3)]
+class RtColoredEmissiveMaterial(_Record):
+    _fields_ = [("kind", C.c_uint32), ("_pad0", C.c_uint32 * 3), ("albedo", F3)]
 
 
-class RtColoredIsotropicMaterial(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("albedo", F3)]
+class RtColoredIsotropicMaterial(_Record):
+    _fields_ = [("kind", C.c_uint32), ("_pad0", C.c_uint32 * 3), ("albedo", F3)]
 
 
-class RtCameraConfig(C.Structure):
-    _fields_ = [("vertical_FOV", C.c_float), ("look_from", F3), ("look_at", F3), ("up", F3),
-                ("defocus_angle", C.c_float), ("focus_distance", C.c_float), ("background", C.c_uint32)]
+class RtCameraConfig(_Record):
+    _fields_ = [("vertical_FOV", C.c_float), ("_pad0", C.c_uint32 * 3), ("look_from", F3), ("look_at", F3), ("up", F3),
+                ("defocus_angle", C.c_float), ("focus_distance", C.c_float), ("background", C.c_uint32), ("_pad1", C.c_uint32)]
 
 
-class RtRenderConfig(C.Structure):
+class RtRenderConfig(_Record):
     _fields_ = [("samples_per_pixel", C.c_uint32), ("max_depth", C.c_uint32),
-                ("pass_counter", C.c_uint32), ("first_sample", C.c_uint32), ("rng_seed", C.c_uint64)]
+                ("pass_counter", C.c_uint32), ("_pad0", C.c_uint32), ("rng_seed", C.c_uint64)]
+
+
+# sizes and offsets of the reference's records (MetalRayTracer/Renderable.h, Config.h, Materials.h with simd types)
+assert [C.sizeof(t) for t in (RtTransform, RtSphere, RtCylinder, RtCuboid, RtQuad, RtCameraConfig, RtRenderConfig)] == \
+    [64, 80, 96, 128, 96, 80, 24]
+assert [C.sizeof(t) for t in (RtColoredLambertianMaterial, RtTexturedLambertianMaterial, RtPerlinNoiseLambertianMaterial,
+                              RtColoredMetalMaterial, RtTexturedMetalMaterial, RtPerlinNoiseMetalMaterial,
+                              RtDielectricMaterial, RtPerlinNoiseTexture)] == [32, 16, 4928, 48, 24, 4944, 8, 4912]
+assert RtSphere.material_offset.offset == 72 and RtQuad.material_offset.offset == 88 and RtCuboid.material_offset.offset == 80
+assert RtCameraConfig.look_from.offset == 16 and RtCameraConfig.background.offset == 72 and RtRenderConfig.rng_seed.offset == 16
+assert RtPerlinNoiseTexture.vectors.offset == 48 and RtPerlinNoiseTexture.permutations.offset == 4144
+
+
+P3 = C.c_float * 3      # packed float triple of the result records
 
 
 class RtHit(C.Structure):
-    _fields_ = [("t", C.c_float), ("point", F3), ("normal", F3), ("uv", C.c_float * 2),
+    _fields_ = [("t", C.c_float), ("point", P3), ("normal", P3), ("uv", C.c_float * 2),
                 ("object", C.c_int32), ("material_offset", C.c_uint32), ("front_face", C.c_int32)]
 
 
 class RtEvent(C.Structure):
-    _fields_ = [("t", C.c_float), ("point", F3), ("normal", F3), ("uv", C.c_float * 2),
+    _fields_ = [("t", C.c_float), ("point", P3), ("normal", P3), ("uv", C.c_float * 2),
                 ("material_offset", C.c_uint32), ("is_exit", C.c_int32), ("pad", C.c_int32)]
 
 

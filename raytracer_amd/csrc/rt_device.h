@@ -317,7 +317,9 @@ RT_DEV Surface prim_surface(const RtDevScene &s, uint32_t ref, uint32_t tag, f3 
                 float4 a = q[0], b = q[1], c = q[2];
                 n = mk3(dot(mk3(a.x, a.y, a.z), r.normal), dot(mk3(b.x, b.y, b.z), r.normal), dot(mk3(c.x, c.y, c.z), r.normal));
             }
-            r.u = (atan2f(n.z, -n.x) + RT_PI) * (1.0f / (2.0f * RT_PI));
+            // RenderableImpl.h:83 measures the angle from -x; RayTracingKit/Hittable.swift:188 from +x
+            // with z mirrored: half a turn apart
+            r.u = ((s.kit_convention ? atan2f(-n.z, n.x) : atan2f(n.z, -n.x)) + RT_PI) * (1.0f / (2.0f * RT_PI));
             r.v = acosf(fminf(fmaxf(-n.y, -1.0f), 1.0f)) * (1.0f / RT_PI);
         }
         return r;
@@ -331,7 +333,9 @@ RT_DEV Surface prim_surface(const RtDevScene &s, uint32_t ref, uint32_t tag, f3 
             r.normal = rot(x, mk3(lp.x, 0.0f, lp.z) * rcp(radius));
             r.material = mats[2];
             if (want_uv) {
-                r.u = (atan2f(lp.z, -lp.x) + RT_PI) * (1.0f / (2.0f * RT_PI));
+                // RenderableImpl.h:205; the Kit's u = atan2(z, x) / 2pi may be negative (Hittable.swift:281)
+                r.u = s.kit_convention ? atan2f(lp.z, lp.x) * (1.0f / (2.0f * RT_PI))
+                                       : (atan2f(lp.z, -lp.x) + RT_PI) * (1.0f / (2.0f * RT_PI));
                 r.v = lp.y * rcp(height);
             }
         } else {
@@ -339,8 +343,13 @@ RT_DEV Surface prim_surface(const RtDevScene &s, uint32_t ref, uint32_t tag, f3 
             r.normal = x.c1 * flip;
             r.material = mats[tag];
             float inv2r = rcp(2.0f * radius);
-            r.u = fmaf(lp.z * flip, inv2r, 0.5f);
-            r.v = fmaf(lp.x, inv2r, 0.5f);
+            if (s.kit_convention) {            // Hittable.swift:245,248: (x, z) on both caps
+                r.u = fmaf(lp.x, inv2r, 0.5f);
+                r.v = fmaf(lp.z, inv2r, 0.5f);
+            } else {                           // RenderableImpl.h:113-121
+                r.u = fmaf(lp.z * flip, inv2r, 0.5f);
+                r.v = fmaf(lp.x, inv2r, 0.5f);
+            }
         }
         return r;
     }
@@ -1028,7 +1037,9 @@ RT_DEV bool scatter(const RtDevScene &s, const Material &m, f3 d, const HitRecor
     case 4: case 5: case 6: {      // metal
         f3 refl = madd(h.normal, -2.0f * dot(d, h.normal), d);
         refl = madd(rv, m.fuzz, refl);
-        if (dot(refl, h.normal) < 0.0f) return false;
+        // MaterialsImpl.h:167 absorbs below the surface, RayTracingKit/Material.swift:55 on it too
+        const float side = dot(refl, h.normal);
+        if (s.kit_convention ? side <= 0.0f : side < 0.0f) return false;
         attenuation = material_color<TEXTURES>(s, m, h);
         new_d = normalize3(refl);
         return true;

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,6 +22,28 @@
 #include "../../include/raytracer_amd.h"
 #include "rt_launch.h"
 #include "rt_shared.h"
+
+// The records are the reference's, byte for byte (MetalRayTracer/Renderable.h:13-63,
+// Config.h:18-33, Materials.h:38-93 with 16-byte simd vectors).
+static_assert(sizeof(RtFloat3) == 16 && alignof(RtFloat3) == 16, "vector_float3");
+static_assert(sizeof(RtMatrix3x3) == 48, "matrix_float3x3");
+static_assert(sizeof(RtTransform) == 64 && offsetof(RtTransform, translation) == 48, "Transform");
+static_assert(sizeof(RtSphere) == 80 && offsetof(RtSphere, radius) == 64 && offsetof(RtSphere, material_offset) == 72, "Sphere");
+static_assert(sizeof(RtCylinder) == 96 && offsetof(RtCylinder, height) == 68 && offsetof(RtCylinder, bottom_material_offset) == 72, "Cylinder");
+static_assert(sizeof(RtCuboid) == 128 && offsetof(RtCuboid, size) == 64 && offsetof(RtCuboid, material_offset) == 80, "Cuboid");
+static_assert(sizeof(RtQuad) == 96 && offsetof(RtQuad, normal) == 64 && offsetof(RtQuad, d) == 80 && offsetof(RtQuad, material_offset) == 88, "Quad");
+static_assert(sizeof(RtCameraConfig) == 80 && offsetof(RtCameraConfig, look_from) == 16 && offsetof(RtCameraConfig, up) == 48 &&
+              offsetof(RtCameraConfig, defocus_angle) == 64 && offsetof(RtCameraConfig, background) == 72, "CameraConfig");
+static_assert(sizeof(RtRenderConfig) == 24 && offsetof(RtRenderConfig, rng_seed) == 16, "RenderConfig");
+static_assert(sizeof(RtPerlinNoiseTexture) == 4912 && offsetof(RtPerlinNoiseTexture, vectors) == 48 &&
+              offsetof(RtPerlinNoiseTexture, permutations) == 4144, "PerlinNoiseTexture");
+static_assert(sizeof(RtColoredLambertianMaterial) == 32 && offsetof(RtColoredLambertianMaterial, albedo) == 16, "ColoredLambertianMaterial");
+static_assert(sizeof(RtTexturedLambertianMaterial) == 16 && offsetof(RtTexturedLambertianMaterial, albedo) == 8, "TexturedLambertianMaterial");
+static_assert(sizeof(RtPerlinNoiseLambertianMaterial) == 4928, "PerlinNoiseLambertianMaterial");
+static_assert(sizeof(RtColoredMetalMaterial) == 48 && offsetof(RtColoredMetalMaterial, fuzz) == 32, "ColoredMetalMaterial");
+static_assert(sizeof(RtTexturedMetalMaterial) == 24 && offsetof(RtTexturedMetalMaterial, fuzz) == 16, "TexturedMetalMaterial");
+static_assert(sizeof(RtPerlinNoiseMetalMaterial) == 4944 && offsetof(RtPerlinNoiseMetalMaterial, fuzz) == 4928, "PerlinNoiseMetalMaterial");
+static_assert(sizeof(RtDielectricMaterial) == 8, "DielectricMaterial");
 
 namespace {
 
@@ -84,6 +107,8 @@ struct RtScene {
     uint32_t refill = 48;
     int node_min = -1;      // -1: chosen at render time from what the scene holds
     int node_format = RT_NODES_AUTO;
+    int convention = RT_CONVENTION_METAL;
+    bool profile_phases = false;
     float query_time = 0.f;     // time of rt_first_hit / rt_intervals queries
     bool use_nodes16 = false;
     bool committed = false;
@@ -436,9 +461,29 @@ int push_shape(RtScene *sc, HostShape &&s) {
 }
 
 void set_xf(HostShape &s, const RtTransform &t) {
-    memcpy(s.rot, t.rotation, sizeof(s.rot));
-    memcpy(s.trans, t.translation, sizeof(s.trans));
+    for (int c = 0; c < 3; c++) memcpy(s.rot + 3 * c, &t.rotation.columns[c].x, 12);
+    memcpy(s.trans, &t.translation.x, 12);
 }
+
+// A caller's record may sit at any address (a byte buffer from another language); the
+// 16-byte alignment of the simd types is only promised for copies made here.
+template <class T> T copy_record(const T *p) {
+    T r;
+    memcpy((void *)&r, (const void *)p, sizeof(T));
+    return r;
+}
+
+// Launches go to the scene's / context's device whatever the caller's current device is.
+struct DeviceScope {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceScope(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+        else prev = -1;        // nothing to restore
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 hipStream_t as_stream(void *p) { return (hipStream_t)p; }
 
@@ -453,18 +498,19 @@ void make_camera(const RtCameraConfig &c, int w, int h, RtDevCamera &out) {
     float half = c.vertical_FOV * pi / 360.f;
     float vh = 2.f * std::tan(half) * c.focus_distance;
     float vw = vh * (float)w / (float)h;
+    const float *look_from = &c.look_from.x, *look_at = &c.look_at.x, *up = &c.up.x;
     float wv[3], uv[3], vv[3];
-    sub(c.look_from, c.look_at, wv);
+    sub(look_from, look_at, wv);
     norm(wv);
-    cross(c.up, wv, uv);
+    cross(up, wv, uv);
     norm(uv);
     cross(wv, uv, vv);
     float dr = c.focus_distance * std::tan(c.defocus_angle * pi / 360.f);
     for (int i = 0; i < 3; i++) {
-        out.center[i] = c.look_from[i];
+        out.center[i] = look_from[i];
         out.viewport_u[i] = vw * uv[i];
         out.viewport_v[i] = -vh * vv[i];
-        out.viewport_center[i] = c.look_from[i] - c.focus_distance * wv[i];
+        out.viewport_center[i] = look_from[i] - c.focus_distance * wv[i];
         out.defocus_u[i] = uv[i] * dr;
         out.defocus_v[i] = vv[i] * dr;
     }
@@ -474,13 +520,14 @@ void make_camera(const RtCameraConfig &c, int w, int h, RtDevCamera &out) {
     out.background = c.background;
 }
 
-RtDevRender make_render(const RtRenderConfig &rc, int w, int h) {
+RtDevRender make_render(const RtRenderConfig &rc, uint32_t first_sample, int w, int h) {
     RtDevRender r;
     r.width = (uint32_t)w; r.height = (uint32_t)h;
     r.spp = rc.samples_per_pixel; r.max_depth = rc.max_depth;
-    r.first_sample = rc.first_sample;
+    r.first_sample = first_sample;
     r.seed_lo = (uint32_t)rc.rng_seed; r.seed_hi = (uint32_t)(rc.rng_seed >> 32);
     r.animated = 0;
+    r.band_index = 0; r.band_count = 1;
     return r;
 }
 
@@ -528,66 +575,65 @@ int rt_add_material(RtScene *sc, const void *record, size_t size) {
     float rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t tex = 0;
     auto want = [&](size_t n) { return size == n ? RT_OK : fail(RT_ERR_INVALID, "material record size does not match its kind"); };
-    auto add_perlin = [&](const RtPerlinNoiseTexture &p) {
+    // Fields are read at their offsets with memcpy: the record may sit at any address.
+    auto f32_at = [&](size_t off) { float v; memcpy(&v, (const char *)record + off, 4); return v; };
+    auto albedo_at = [&](size_t off) { rec[4] = f32_at(off); rec[5] = f32_at(off + 4); rec[6] = f32_at(off + 8); };
+    auto image_at = [&](size_t off) {
+        uint64_t id;
+        memcpy(&id, (const char *)record + off, 8);
+        tex = (uint32_t)id;
+        return id < sc->textures.size() ? RT_OK : fail(RT_ERR_INVALID, "texture_ptr does not name a texture added with rt_add_texture_rgb8");
+    };
+    auto add_perlin = [&](size_t off) {
+        const char *p = (const char *)record + off;
         RtDevPerlin d;
-        memcpy(d.colors, p.colors, sizeof(d.colors));
-        d.frequency = p.frequency;
-        d.turbulence = p.turbulence;
-        memcpy(d.vectors, p.vectors, sizeof(d.vectors));
-        memcpy(d.permutations, p.permutations, sizeof(d.permutations));
+        for (int i = 0; i < 2; i++) memcpy(d.colors[i], p + offsetof(RtPerlinNoiseTexture, colors) + 16 * i, 12);
+        memcpy(&d.frequency, p + offsetof(RtPerlinNoiseTexture, frequency), 4);
+        memcpy(&d.turbulence, p + offsetof(RtPerlinNoiseTexture, turbulence), 4);
+        for (int i = 0; i < RT_PERLIN_TABLE_SIZE; i++) memcpy(d.vectors[i], p + offsetof(RtPerlinNoiseTexture, vectors) + 16 * i, 12);
+        memcpy(d.permutations, p + offsetof(RtPerlinNoiseTexture, permutations), sizeof(d.permutations));
         sc->perlin.push_back(d);
         return (uint32_t)sc->perlin.size() - 1;
     };
     switch (kind) {
     case rt_material_kind_lambertian_colored:
     case rt_material_kind_emissive_colored:
-    case rt_material_kind_isotropic_colored: {
+    case rt_material_kind_isotropic_colored:
         if (want(sizeof(RtColoredLambertianMaterial)) < 0) return RT_ERR_INVALID;
-        const auto *m = (const RtColoredLambertianMaterial *)record;
-        rec[4] = m->albedo[0]; rec[5] = m->albedo[1]; rec[6] = m->albedo[2];
+        albedo_at(offsetof(RtColoredLambertianMaterial, albedo));
         break;
-    }
-    case rt_material_kind_lambertian_textured: {
+    case rt_material_kind_lambertian_textured:
         if (want(sizeof(RtTexturedLambertianMaterial)) < 0) return RT_ERR_INVALID;
-        tex = ((const RtTexturedLambertianMaterial *)record)->albedo.texture_id;
-        if (tex >= sc->textures.size()) return fail(RT_ERR_INVALID, "texture_id does not name a texture");
+        if (image_at(offsetof(RtTexturedLambertianMaterial, albedo)) < 0) return RT_ERR_INVALID;
         break;
-    }
     case rt_material_kind_lambertian_perlin_noise:
         if (want(sizeof(RtPerlinNoiseLambertianMaterial)) < 0) return RT_ERR_INVALID;
-        tex = add_perlin(((const RtPerlinNoiseLambertianMaterial *)record)->albedo);
+        tex = add_perlin(offsetof(RtPerlinNoiseLambertianMaterial, albedo));
         break;
-    case rt_material_kind_metal_colored: {
+    case rt_material_kind_metal_colored:
         if (want(sizeof(RtColoredMetalMaterial)) < 0) return RT_ERR_INVALID;
-        const auto *m = (const RtColoredMetalMaterial *)record;
-        rec[4] = m->albedo[0]; rec[5] = m->albedo[1]; rec[6] = m->albedo[2];
-        rec[2] = m->fuzz;
+        albedo_at(offsetof(RtColoredMetalMaterial, albedo));
+        rec[2] = f32_at(offsetof(RtColoredMetalMaterial, fuzz));
         break;
-    }
-    case rt_material_kind_metal_textured: {
+    case rt_material_kind_metal_textured:
         if (want(sizeof(RtTexturedMetalMaterial)) < 0) return RT_ERR_INVALID;
-        const auto *m = (const RtTexturedMetalMaterial *)record;
-        tex = m->albedo.texture_id;
-        if (tex >= sc->textures.size()) return fail(RT_ERR_INVALID, "texture_id does not name a texture");
-        rec[2] = m->fuzz;
+        if (image_at(offsetof(RtTexturedMetalMaterial, albedo)) < 0) return RT_ERR_INVALID;
+        rec[2] = f32_at(offsetof(RtTexturedMetalMaterial, fuzz));
         break;
-    }
-    case rt_material_kind_metal_perlin_noise: {
+    case rt_material_kind_metal_perlin_noise:
         if (want(sizeof(RtPerlinNoiseMetalMaterial)) < 0) return RT_ERR_INVALID;
-        const auto *m = (const RtPerlinNoiseMetalMaterial *)record;
-        tex = add_perlin(m->albedo);
-        rec[2] = m->fuzz;
+        tex = add_perlin(offsetof(RtPerlinNoiseMetalMaterial, albedo));
+        rec[2] = f32_at(offsetof(RtPerlinNoiseMetalMaterial, fuzz));
         break;
-    }
     case rt_material_kind_lambertian_kit_texture:
     case rt_material_kind_emissive_kit_texture:
         if (want(sizeof(RtKitTexturedMaterial)) < 0) return RT_ERR_INVALID;
-        tex = ((const RtKitTexturedMaterial *)record)->texture;
+        memcpy(&tex, (const char *)record + offsetof(RtKitTexturedMaterial, texture), 4);
         if (tex >= sc->kit_textures.size()) return fail(RT_ERR_INVALID, "texture does not name a texture added with rt_add_kit_texture");
         break;
     case rt_material_kind_dielectric:
         if (want(sizeof(RtDielectricMaterial)) < 0) return RT_ERR_INVALID;
-        rec[3] = ((const RtDielectricMaterial *)record)->refraction_index;
+        rec[3] = f32_at(offsetof(RtDielectricMaterial, refraction_index));
         break;
     default:
         return fail(RT_ERR_INVALID, "unknown material kind");
@@ -669,59 +715,63 @@ int rt_add_texture_rgb8(RtScene *sc, int width, int height, const uint8_t *rgb) 
     return (int)sc->textures.size() - 1;
 }
 
-int rt_shape_sphere(RtScene *sc, const RtSphere *p) {
-    if (!sc || !p) return fail(RT_ERR_INVALID, "null argument");
-    if (!(p->radius > 0.f)) return fail(RT_ERR_INVALID, "sphere radius must be positive");
-    if (check_material(sc, p->material_offset) < 0) return RT_ERR_INVALID;
+int rt_shape_sphere(RtScene *sc, const RtSphere *rec) {
+    if (!sc || !rec) return fail(RT_ERR_INVALID, "null argument");
+    const RtSphere p = copy_record(rec);
+    if (!(p.radius > 0.f)) return fail(RT_ERR_INVALID, "sphere radius must be positive");
+    if (check_material(sc, p.material_offset) < 0) return RT_ERR_INVALID;
     HostShape s;
     s.kind = RT_KIND_SPHERE;
-    set_xf(s, p->transform);
-    s.radius = p->radius;
-    s.mat[0] = (uint32_t)p->material_offset;
+    set_xf(s, p.transform);
+    s.radius = p.radius;
+    s.mat[0] = (uint32_t)p.material_offset;
     return push_shape(sc, std::move(s));
 }
 
-int rt_shape_cylinder(RtScene *sc, const RtCylinder *p) {
-    if (!sc || !p) return fail(RT_ERR_INVALID, "null argument");
-    if (!(p->radius >= 0.f) || !(p->height >= 0.f)) return fail(RT_ERR_INVALID, "cylinder radius/height must not be negative");
-    if (check_material(sc, p->bottom_material_offset) < 0 || check_material(sc, p->top_material_offset) < 0 ||
-        check_material(sc, p->side_material_offset) < 0)
+int rt_shape_cylinder(RtScene *sc, const RtCylinder *rec) {
+    if (!sc || !rec) return fail(RT_ERR_INVALID, "null argument");
+    const RtCylinder p = copy_record(rec);
+    if (!(p.radius >= 0.f) || !(p.height >= 0.f)) return fail(RT_ERR_INVALID, "cylinder radius/height must not be negative");
+    if (check_material(sc, p.bottom_material_offset) < 0 || check_material(sc, p.top_material_offset) < 0 ||
+        check_material(sc, p.side_material_offset) < 0)
         return RT_ERR_INVALID;
     HostShape s;
     s.kind = RT_KIND_CYLINDER;
-    set_xf(s, p->transform);
-    s.radius = p->radius; s.height = p->height;
-    s.mat[0] = (uint32_t)p->bottom_material_offset;
-    s.mat[1] = (uint32_t)p->top_material_offset;
-    s.mat[2] = (uint32_t)p->side_material_offset;
+    set_xf(s, p.transform);
+    s.radius = p.radius; s.height = p.height;
+    s.mat[0] = (uint32_t)p.bottom_material_offset;
+    s.mat[1] = (uint32_t)p.top_material_offset;
+    s.mat[2] = (uint32_t)p.side_material_offset;
     return push_shape(sc, std::move(s));
 }
 
-int rt_shape_cuboid(RtScene *sc, const RtCuboid *p) {
-    if (!sc || !p) return fail(RT_ERR_INVALID, "null argument");
+int rt_shape_cuboid(RtScene *sc, const RtCuboid *rec) {
+    if (!sc || !rec) return fail(RT_ERR_INVALID, "null argument");
+    const RtCuboid p = copy_record(rec);
     HostShape s;
     s.kind = RT_KIND_CUBOID;
-    set_xf(s, p->transform);
-    for (int i = 0; i < 3; i++) s.size[i] = p->size[i];
+    set_xf(s, p.transform);
+    memcpy(s.size, &p.size.x, 12);
     for (int i = 0; i < 6; i++) {
-        if (check_material(sc, p->material_offset[i]) < 0) return RT_ERR_INVALID;
-        s.mat[i] = (uint32_t)p->material_offset[i];
+        if (check_material(sc, p.material_offset[i]) < 0) return RT_ERR_INVALID;
+        s.mat[i] = (uint32_t)p.material_offset[i];
     }
     return push_shape(sc, std::move(s));
 }
 
-int rt_shape_quad(RtScene *sc, const RtQuad *p) {
-    if (!sc || !p) return fail(RT_ERR_INVALID, "null argument");
-    if (check_material(sc, p->material_offset) < 0) return RT_ERR_INVALID;
+int rt_shape_quad(RtScene *sc, const RtQuad *rec) {
+    if (!sc || !rec) return fail(RT_ERR_INVALID, "null argument");
+    const RtQuad p = copy_record(rec);
+    if (check_material(sc, p.material_offset) < 0) return RT_ERR_INVALID;
     HostShape s;
     s.kind = RT_KIND_QUAD;
-    memcpy(s.quad + 0, p->origin, 12);
-    memcpy(s.quad + 3, p->u, 12);
-    memcpy(s.quad + 6, p->v, 12);
-    memcpy(s.quad + 9, p->w, 12);
-    memcpy(s.quad + 12, p->normal, 12);
-    s.quad[15] = p->d;
-    s.mat[0] = (uint32_t)p->material_offset;
+    memcpy(s.quad + 0, &p.origin.x, 12);
+    memcpy(s.quad + 3, &p.u.x, 12);
+    memcpy(s.quad + 6, &p.v.x, 12);
+    memcpy(s.quad + 9, &p.w.x, 12);
+    memcpy(s.quad + 12, &p.normal.x, 12);
+    s.quad[15] = p.d;
+    s.mat[0] = (uint32_t)p.material_offset;
     return push_shape(sc, std::move(s));
 }
 
@@ -738,6 +788,8 @@ int rt_shape_csg(RtScene *sc, int op, int n_children, const int *children) {
         if (sc->shapes[c].kind == RT_KIND_CDV)
             return fail(RT_ERR_INVALID, "a constant-density volume cannot be a CSG operand (the reference's Composition "
                                         "builds its children without a generator, RenderableImpl.h:645-654)");
+        if (sc->shapes[c].kind == RT_KIND_MOTION)
+            return fail(RT_ERR_INVALID, "a moving shape cannot be a CSG operand: wrap the whole CSG shape in the motion instead");
         if (sc->shapes[c].parent >= 0 || sc->shapes[c].object >= 0) return fail(RT_ERR_INVALID, "shape is already in use");
         s.children.push_back(c);
     }
@@ -758,6 +810,7 @@ int rt_shape_cdv(RtScene *sc, int base, float density) {
     if (!sc || base < 0 || base >= (int)sc->shapes.size()) return fail(RT_ERR_INVALID, "bad base shape id");
     if (!(density > 0.f)) return fail(RT_ERR_INVALID, "density must be positive");
     if (sc->shapes[base].kind == RT_KIND_CDV) return fail(RT_ERR_INVALID, "a volume cannot wrap a volume");
+    if (sc->shapes[base].kind == RT_KIND_MOTION) return fail(RT_ERR_INVALID, "a volume cannot wrap a moving shape");
     if (sc->shapes[base].parent >= 0 || sc->shapes[base].object >= 0) return fail(RT_ERR_INVALID, "shape is already in use");
     HostShape s;
     s.kind = RT_KIND_CDV;
@@ -829,8 +882,8 @@ int rt_scene_commit(RtScene *sc) {
     if (!sc) return fail(RT_ERR_INVALID, "null scene");
     if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
     if (!sc->ctx) return fail(RT_ERR_STATE, "scene was created without a device context");
-    hipError_t he = hipSetDevice(sc->ctx->device);
-    if (he != hipSuccess) return fail_hip(he, "hipSetDevice");
+    DeviceScope on_device(sc->ctx->device);
+    if (!on_device.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
     sc->stats = RtSceneStats{};
 
     // ---- device slots for every shape (objects or not: rt_intervals may ask for any)
@@ -1047,6 +1100,7 @@ int rt_scene_commit(RtScene *sc) {
     if ((rc = upload(sc, sc->kit_perlin, &d.kit_perlin)) < 0) return rc;
     d.root = root;
     d.n_nodes = (uint32_t)(bld.nodes.size() / 16);
+    d.kit_convention = sc->convention == RT_CONVENTION_KIT ? 1u : 0u;
     sc->feat = feat;
 
     RtSceneStats &st = sc->stats;
@@ -1089,6 +1143,18 @@ int rt_scene_set_option(RtScene *sc, int option, int value) {
         if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "node minimum must be 0..64");
         sc->node_min = value;
         return RT_OK;
+    case RT_OPTION_KERNEL_TIMING:
+        if (!value) sc->timer.collect();
+        sc->timer.enabled = value != 0;
+        return RT_OK;
+    case RT_OPTION_PROFILE_PHASES:
+        sc->profile_phases = value != 0;
+        return RT_OK;
+    case RT_OPTION_CONVENTION:
+        if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
+        if (value != RT_CONVENTION_METAL && value != RT_CONVENTION_KIT) return fail(RT_ERR_INVALID, "unknown convention");
+        sc->convention = value;
+        return RT_OK;
     default:
         return fail(RT_ERR_INVALID, "unknown option");
     }
@@ -1105,6 +1171,8 @@ int rt_first_hit(RtScene *sc, const float *rays_dev, int n, float tmin, float tm
                  void *stream) {
     if (!sc || n < 0 || (n > 0 && (!rays_dev || !out_dev))) return fail(RT_ERR_INVALID, "bad argument");
     if (!sc->committed) return fail(RT_ERR_STATE, "scene not committed");
+    DeviceScope on_device(sc->ctx->device);
+    if (!on_device.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
     hipError_t e = rt_launch_first_hit(sc->dev, sc->feat, rays_dev, n, tmin, tmax, volume_key, sc->query_time, out_dev, as_stream(stream));
     return e == hipSuccess ? RT_OK : fail_hip(e, "first-hit launch");
 }
@@ -1115,6 +1183,8 @@ int rt_intervals(RtScene *sc, int shape, const float *rays_dev, int n, const flo
     if (!sc->committed) return fail(RT_ERR_STATE, "scene not committed");
     if (shape < 0 || shape >= (int)sc->shapes.size()) return fail(RT_ERR_INVALID, "bad shape id");
     if (scripted_u_dev && n_scripted <= 0) return fail(RT_ERR_INVALID, "scripted values given but n_scripted <= 0");
+    DeviceScope on_device(sc->ctx->device);
+    if (!on_device.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
     const HostShape &s = sc->shapes[shape];
     uint32_t object = s.object >= 0 ? (uint32_t)s.object : 0u;
     hipError_t e = rt_launch_intervals(sc->dev, s.ref, rays_dev, n, scripted_u_dev, n_scripted, volume_key, object,
@@ -1122,52 +1192,109 @@ int rt_intervals(RtScene *sc, int shape, const float *rays_dev, int n, const flo
     return e == hipSuccess ? RT_OK : fail_hip(e, "intervals launch");
 }
 
-int rt_camera_rays(RtContext *ctx, const RtCameraConfig *cc, const RtRenderConfig *rc, int width, int height, int x0,
-                   int y0, int w, int h, float *rays_out_dev, void *stream) {
+int rt_camera_rays(RtContext *ctx, const RtCameraConfig *cc, const RtRenderConfig *rc, uint32_t first_sample, int width,
+                   int height, int x0, int y0, int w, int h, float *rays_out_dev, void *stream) {
     if (!ctx || !cc || !rc || !rays_out_dev || width <= 0 || height <= 0 || w < 0 || h < 0)
         return fail(RT_ERR_INVALID, "bad argument");
+    DeviceScope on_device(ctx->device);
+    if (!on_device.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
     RtDevCamera cam;
-    make_camera(*cc, width, height, cam);
-    RtDevRender r = make_render(*rc, width, height);
+    make_camera(copy_record(cc), width, height, cam);
+    RtDevRender r = make_render(copy_record(rc), first_sample, width, height);
     hipError_t e = rt_launch_camera_rays(cam, r, x0, y0, w, h, rays_out_dev, as_stream(stream));
     return e == hipSuccess ? RT_OK : fail_hip(e, "camera-rays launch");
 }
 
+int rt_rng_words(RtContext *ctx, const uint32_t *streams_dev, int n, int words_per_stream, uint32_t *out_dev,
+                 uint32_t *wyrand_out_dev, void *stream) {
+    if (!ctx || n < 0 || words_per_stream < 0 || (n > 0 && (!streams_dev || !out_dev || !wyrand_out_dev)))
+        return fail(RT_ERR_INVALID, "bad argument");
+    DeviceScope on_device(ctx->device);
+    if (!on_device.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
+    hipError_t e = rt_launch_rng_words(streams_dev, n, words_per_stream, out_dev, wyrand_out_dev, as_stream(stream));
+    return e == hipSuccess ? RT_OK : fail_hip(e, "rng-words launch");
+}
+
+// The fused workspace is sized for the current device (the call has no context argument); a
+// caller that drives several devices asks with the scene's device current.
 size_t rt_render_workspace_size(int pipeline, int width, int height) {
     if (width <= 0 || height <= 0) return 0;
-    if (pipeline == RT_PIPELINE_FUSED) return rt_fused_workspace_bytes();
+    if (pipeline == RT_PIPELINE_FUSED) return rt_fused_workspace_bytes(rt_current_device_cus());
     return rt_wavefront_bytes((uint32_t)width * (uint32_t)height * RT_WAVEFRONT_BATCH_SPP);
 }
 
-int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, int pipeline, int width, int height,
-              float *accum_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
-    if (!sc || !cc || !rc || !accum_dev || !workspace_dev || width <= 0 || height <= 0)
-        return fail(RT_ERR_INVALID, "bad argument");
+int rt_band_rows(int height, int band_index, int band_count) {
+    if (height <= 0 || band_count <= 0 || band_index < 0 || band_index >= band_count) return fail(RT_ERR_INVALID, "bad band arguments");
+    int bands = (height + 7) / 8;
+    int mine = band_index < bands ? (bands - band_index + band_count - 1) / band_count : 0;
+    return 8 * mine;
+}
+
+namespace {
+
+// Knobs of the fused kernel: node steps go on while 8 lanes want one.  Sphere tests cost about
+// one node step, so in sphere scenes 20 lanes waiting at a leaf get their turn even then; tests
+// of cylinders, boxes, CSG shapes and volumes cost several node steps and wait for fuller waves.
+uint32_t fused_knobs(const RtScene *sc, const RtDevCamera &cam) {
+    const uint32_t node_min = sc->node_min >= 0 ? (uint32_t)sc->node_min : 8u;
+    return sc->refill | (node_min << 8) | (sc->profile_phases ? 0x10000u : 0u) | (sc->use_nodes16 ? 0x20000u : 0u) |
+           ((cam.defocus ? 16u : 0u) << 18) | (((sc->feat & 1u) ? 65u : 20u) << 25);
+}
+
+int render_checks(const RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, const float *accum_dev, int width, int height) {
+    if (!sc || !cc || !rc || !accum_dev || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "bad argument");
     if (!sc->committed) return fail(RT_ERR_STATE, "scene not committed");
     if ((uint64_t)width * (uint64_t)height > (1u << 28) || width > 65535 || height > 65535)     // a lane keeps its pixel as x | y << 16
         return fail(RT_ERR_LIMIT, "image too large");
+    return RT_OK;
+}
+
+}  // namespace
+
+int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, uint32_t first_sample, int pipeline, int width,
+              int height, float *accum_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
+    int chk = render_checks(sc, cc, rc, accum_dev, width, height);
+    if (chk < 0) return chk;
+    if (!workspace_dev) return fail(RT_ERR_INVALID, "bad argument");
+    DeviceScope on_device(sc->ctx->device);
+    if (!on_device.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
     RtDevCamera cam;
-    make_camera(*cc, width, height, cam);
-    RtDevRender r = make_render(*rc, width, height);
+    make_camera(copy_record(cc), width, height, cam);
+    RtDevRender r = make_render(copy_record(rc), first_sample, width, height);
     r.animated = (sc->feat & RT_FEAT_MOTION) ? 1u : 0u;
     hipError_t e;
     if (pipeline == RT_PIPELINE_FUSED) {
         if (workspace_bytes < RT_FUSED_HEADER) return fail(RT_ERR_INVALID, "workspace too small");
-        // node steps go on while 8 lanes want one.  Sphere tests cost about one node step, so in
-        // sphere scenes 20 lanes waiting at a leaf get their turn even then; tests of cylinders,
-        // boxes, CSG shapes and volumes cost several node steps and wait for fuller waves
-        const uint32_t node_min = sc->node_min >= 0 ? (uint32_t)sc->node_min : 8u;
-        const uint32_t knobs = sc->refill | (node_min << 8) | (getenv("RT_PROFILE_PHASES") ? 0x10000u : 0u) |
-                               (sc->use_nodes16 ? 0x20000u : 0u) | ((cam.defocus ? 16u : 0u) << 18) |
-                               (((sc->feat & 1u) ? 65u : 20u) << 25);
-        e = rt_render_fused(sc->dev, sc->feat, sc->stats.bvh_depth, cam, r, knobs, accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);
+        e = rt_render_fused(sc->dev, sc->feat, sc->stats.bvh_depth, cam, r, fused_knobs(sc, cam), accum_dev, workspace_dev,
+                            workspace_bytes, as_stream(stream), &sc->timer, sc->ctx->cus);
     } else if (pipeline == RT_PIPELINE_WAVEFRONT) {
         if (workspace_bytes < rt_wavefront_bytes((uint32_t)width * (uint32_t)height))
             return fail(RT_ERR_INVALID, "workspace too small");
-        e = rt_render_wavefront(sc->dev, sc->feat, cam, r, accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer);
+        e = rt_render_wavefront(sc->dev, sc->feat, cam, r, accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer,
+                                sc->ctx->cus);
     } else {
         return fail(RT_ERR_INVALID, "unknown pipeline");
     }
+    return e == hipSuccess ? RT_OK : fail_hip(e, "render");
+}
+
+int rt_render_bands(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, uint32_t first_sample, int band_index,
+                    int band_count, int width, int height, float *accum_bands_dev, void *workspace_dev, size_t workspace_bytes,
+                    void *stream) {
+    int chk = render_checks(sc, cc, rc, accum_bands_dev, width, height);
+    if (chk < 0) return chk;
+    if (!workspace_dev || workspace_bytes < RT_FUSED_HEADER) return fail(RT_ERR_INVALID, "workspace too small");
+    if (band_count <= 0 || band_index < 0 || band_index >= band_count) return fail(RT_ERR_INVALID, "bad band arguments");
+    DeviceScope on_device(sc->ctx->device);
+    if (!on_device.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
+    RtDevCamera cam;
+    make_camera(copy_record(cc), width, height, cam);
+    RtDevRender r = make_render(copy_record(rc), first_sample, width, height);
+    r.animated = (sc->feat & RT_FEAT_MOTION) ? 1u : 0u;
+    r.band_index = (uint32_t)band_index;
+    r.band_count = (uint32_t)band_count;
+    hipError_t e = rt_render_fused(sc->dev, sc->feat, sc->stats.bvh_depth, cam, r, fused_knobs(sc, cam), accum_bands_dev, workspace_dev,
+                                   workspace_bytes, as_stream(stream), &sc->timer, sc->ctx->cus);
     return e == hipSuccess ? RT_OK : fail_hip(e, "render");
 }
 
@@ -1175,7 +1302,9 @@ int rt_resolve_rgb8(RtContext *ctx, const float *accum_dev, uint32_t n_samples, 
                     uint8_t *rgbx_out_dev, void *stream) {
     if (!ctx || !accum_dev || !rgbx_out_dev || width <= 0 || height <= 0 || n_samples == 0)
         return fail(RT_ERR_INVALID, "bad argument");
-    hipError_t e = rt_launch_resolve(accum_dev, 1.f / (float)n_samples, width, height, rgbx_out_dev, as_stream(stream));
+    DeviceScope on_device(ctx->device);
+    if (!on_device.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
+    hipError_t e = rt_launch_resolve(accum_dev, (float)n_samples, width, height, rgbx_out_dev, as_stream(stream));
     return e == hipSuccess ? RT_OK : fail_hip(e, "resolve launch");
 }
 
@@ -1184,6 +1313,8 @@ int rt_progressive_present(RtContext *ctx, const float *pass_sum_dev, uint32_t s
     if (!ctx || !pass_sum_dev || !acc_rgb10a2_dev || !bgra8_out_dev || width <= 0 || height <= 0)
         return fail(RT_ERR_INVALID, "bad argument");
     if (samples_per_pixel == 0 || pass_counter == 0) return fail(RT_ERR_INVALID, "samples_per_pixel and pass_counter start at 1");
+    DeviceScope on_device(ctx->device);
+    if (!on_device.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
     hipError_t e = rt_launch_progressive_present(pass_sum_dev, samples_per_pixel, pass_counter, width, height, acc_rgb10a2_dev,
                                                  bgra8_out_dev, as_stream(stream));
     return e == hipSuccess ? RT_OK : fail_hip(e, "present launch");
@@ -1191,6 +1322,7 @@ int rt_progressive_present(RtContext *ctx, const float *pass_sum_dev, uint32_t s
 
 int rt_kernel_time(RtScene *sc, int reset, double *total_ms, uint64_t *launches, const char **kernel_name) {
     if (!sc) return fail(RT_ERR_INVALID, "null scene");
+    DeviceScope on_device(sc->ctx ? sc->ctx->device : 0);
     sc->timer.collect();
     if (total_ms) *total_ms = sc->timer.total_ms;
     if (launches) *launches = sc->timer.launches;

@@ -192,18 +192,37 @@ __global__ __launch_bounds__(RT_BLOCK) void k_camera_rays(RtDevCamera cam, RtDev
     r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
 }
 
-// Camera.swift:92, Vector3D.swift:185-191,208-211: mean, gamma 2, quantise.
-__global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float *accum, float inv_samples, int npix, uint8_t *rgbx) {
+// Camera.swift:92, Vector3D.swift:185-191,208-211 in float: sum / n, square root, min with 1,
+// floor(nextDown(256) * x).  Every operation is a correctly rounded single one (contraction off;
+// `/` and sqrtf are the IEEE ones under hipcc's defaults), so the bytes are those of a plain IEEE
+// evaluation of the same expressions.  A negative or NaN sum (the Kit's precondition would trap)
+// gives 0.
+__global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float *accum, float n_samples, int npix, uint8_t *rgbx) {
+#pragma clang fp contract(off)
     int i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= npix) return;
     uint32_t px = 0;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        float v = fminf(fsqrt(fmaxf(accum[3 * (size_t)i + c] * inv_samples, 0.f)), 1.f);
+        float mean = accum[3 * (size_t)i + c] / n_samples;
+        float v = mean > 0.f ? fminf(sqrtf(mean), 1.f) : 0.f;
         uint32_t q = (uint32_t)floorf(255.99998f * v);
         px |= (q > 255u ? 255u : q) << (8 * c);
     }
     ((uint32_t *)rgbx)[i] = px;
+}
+
+// Raw generator words for bit-exact comparison with a host implementation.
+__global__ __launch_bounds__(RT_BLOCK) void k_rng_words(const uint32_t *streams, int n, int words, uint32_t *out, uint32_t *wy_out) {
+    int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *r = streams + 8 * (size_t)i;
+    const uint64_t seed = ((uint64_t)r[1] << 32) | r[0];
+    Pcg g = sample_stream(seed, r[2], r[3], r[4]);
+    for (int k = 0; k < words; k++) out[(size_t)i * words + k] = pcg_next(g);
+    const uint64_t w = wyrand_at(seed, r[2]);
+    wy_out[2 * (size_t)i] = (uint32_t)w;
+    wy_out[2 * (size_t)i + 1] = (uint32_t)(w >> 32);
 }
 
 // Shaders.metal:151-158.  Every float operation is a correctly rounded single one
@@ -486,11 +505,13 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
     // with it, while the lanes still walking paths of earlier items finish those on the side.
     // The tile sums in LDS always belong to the current item: they are flushed when the wave
     // moves on, and a straggler adds its radiance to memory itself ("direct").
-    uint32_t next = 0, total = 0, tx0 = 0, ty0 = 0, s_begin = 0;
+    // (tx0, ty0): the tile's corner in the accumulator; gy0: its first row in the image (they
+    // differ when the accumulator holds one shard's bands only)
+    uint32_t next = 0, total = 0, tx0 = 0, ty0 = 0, gy0 = 0, s_begin = 0;
     bool more = true;                  // the item counter has not run out yet
     bool has_path = false, direct = false;
     f3 thr = mk3(0, 0, 0), rad = mk3(0, 0, 0);
-    uint32_t depth = 0, pxy = 0;       // pixel of the lane's path: x | y << 16
+    uint32_t depth = 0, pxy = 0;       // accumulator pixel of the lane's path: x | y << 16
     uint64_t key = 0;
     float time = 0.f;                  // the sample's time; only scenes with moving objects draw one
     Pcg g;
@@ -531,7 +552,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
         if (next >= total && more) {
             if (total) {
                 uint32_t x = tx0 + (lane & 7u), y = ty0 + (lane >> 3);
-                if (x < rc.width && y < rc.height) {
+                if (x < rc.width && gy0 + (lane >> 3) < rc.height) {
                     // other chunks of the same tile may be in flight elsewhere: atomics
                     float *dst = accum + 3 * ((size_t)y * rc.width + x);
                     atomicAdd(dst + 0, acc[3u * lane + 0u]);
@@ -551,8 +572,10 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
                 const uint32_t tile = item % n_tiles, chunk = item / n_tiles;
                 s_begin = chunk * chunk_spp;
                 total = (min(rc.spp, s_begin + chunk_spp) - s_begin) * 64u;
+                const uint32_t tile_row = tile / tiles_x;
                 tx0 = (tile % tiles_x) * 8u;
-                ty0 = (tile / tiles_x) * 8u;
+                ty0 = tile_row * 8u;
+                gy0 = (tile_row * rc.band_count + rc.band_index) * 8u;
             }
         }
         RT_PROF_BEGIN();
@@ -572,7 +595,8 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
             if (!has_path) {
                 uint32_t k = next + prefix_rank(need);
                 if (k < total) {
-                    uint32_t x = tx0 + (k & 7u), y = ty0 + ((k >> 3) & 7u);
+                    const uint32_t row = (k >> 3) & 7u;
+                    uint32_t x = tx0 + (k & 7u), y = gy0 + row;
                     if (x < rc.width && y < rc.height) {
                         g = sample_stream(seed, rc.first_sample + s_begin + (k >> 6), x, y);
                         camera_ray(cam_now, x, y, g, o, d);
@@ -580,7 +604,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
                         thr = mk3(1, 1, 1);
                         rad = mk3(0, 0, 0);
                         depth = 0;
-                        pxy = x | (y << 16);
+                        pxy = x | ((ty0 + row) << 16);      // where the sample is accumulated
                         direct = false;
                         has_path = true;
                         start = true;
@@ -695,10 +719,17 @@ hipError_t rt_launch_camera_rays(const RtDevCamera &cam, const RtDevRender &rc, 
     return hipGetLastError();
 }
 
-hipError_t rt_launch_resolve(const float *accum, float inv_samples, int width, int height, uint8_t *rgbx, hipStream_t stream) {
+hipError_t rt_launch_resolve(const float *accum, float n_samples, int width, int height, uint8_t *rgbx, hipStream_t stream) {
     int npix = width * height;
     if (npix <= 0) return hipSuccess;
-    k_resolve<<<blocks_for(npix), RT_BLOCK, 0, stream>>>(accum, inv_samples, npix, rgbx);
+    k_resolve<<<blocks_for(npix), RT_BLOCK, 0, stream>>>(accum, n_samples, npix, rgbx);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_rng_words(const uint32_t *streams, int n, int words_per_stream, uint32_t *out, uint32_t *wyrand_out,
+                               hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    k_rng_words<<<blocks_for(n), RT_BLOCK, 0, stream>>>(streams, n, words_per_stream, out, wyrand_out);
     return hipGetLastError();
 }
 
@@ -711,13 +742,12 @@ hipError_t rt_launch_progressive_present(const float *pass_sum, uint32_t spp, ui
     return hipGetLastError();
 }
 
-static int device_cus();
 // Header (work counter, diagnostics, camera) + the deep-stack columns of the largest grid.
-size_t rt_fused_workspace_bytes() {
-    return RT_FUSED_DEEP_OFFSET + (size_t)device_cus() * 8u * RT_BLOCK * (RT_STACK_DEPTH - 16) * 4u;
+size_t rt_fused_workspace_bytes(int cus) {
+    return RT_FUSED_DEEP_OFFSET + (size_t)cus * 8u * RT_BLOCK * (RT_STACK_DEPTH - 16) * 4u;
 }
 
-static int device_cus() {
+int rt_current_device_cus() {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     return cus > 0 ? cus : 256;
@@ -751,7 +781,7 @@ static hipError_t wavefront_batch(const RtDevScene &s, const RtDevCamera &cam, c
 }
 
 hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc, float *accum,
-                               void *workspace, size_t workspace_bytes, hipStream_t stream, RtKernelTimer *timer) {
+                               void *workspace, size_t workspace_bytes, hipStream_t stream, RtKernelTimer *timer, int cus) {
     uint32_t npix = rc.width * rc.height;
     if (npix == 0 || rc.spp == 0) return hipSuccess;
     if (workspace_bytes < rt_wavefront_bytes(npix)) return hipErrorInvalidValue;
@@ -769,7 +799,7 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
         RtDevRender r = rc;
         r.first_sample = first + s0;
         r.spp = batch;
-        int grid = std::min(blocks_for((size_t)npix * batch), device_cus() * 8);
+        int grid = std::min(blocks_for((size_t)npix * batch), cus * 8);
         grid = (grid + (int)RT_WF_SHARDS - 1) / (int)RT_WF_SHARDS * (int)RT_WF_SHARDS;
         hipError_t e;
         switch (feat & 7u) {
@@ -787,12 +817,23 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
 
 template <int FEAT, int STACK, int WPS, bool NODE16, bool DEEP = false>
 static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, const RtDevRender &rc, float *accum,
-                               uint32_t *counter, uint32_t knobs, hipStream_t stream, RtKernelTimer *timer) {
-    uint32_t tiles_x = (rc.width + 7u) / 8u, tiles_y = (rc.height + 7u) / 8u, n_tiles = tiles_x * tiles_y;
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS, NODE16, DEEP>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
+                               uint32_t *counter, uint32_t knobs, hipStream_t stream, RtKernelTimer *timer, int cus) {
+    // tile rows of this shard (all of them when band_count is 1)
+    const uint32_t all_rows = (rc.height + 7u) / 8u;
+    const uint32_t tiles_y = rc.band_index < all_rows ? (all_rows - rc.band_index + rc.band_count - 1u) / rc.band_count : 0u;
+    const uint32_t tiles_x = (rc.width + 7u) / 8u, n_tiles = tiles_x * tiles_y;
+    if (n_tiles == 0) return hipSuccess;
+    // workgroups per compute unit of this instantiation: asked once per device
+    static int occ_of_device[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int occ = (dev >= 0 && dev < 64) ? occ_of_device[dev] : 0;
+    if (occ < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS, NODE16, DEEP>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
+        if (dev >= 0 && dev < 64) occ_of_device[dev] = occ;
+    }
     if (DEEP) occ = std::min(occ, 8);        // the deep-stack columns are sized for 8 workgroups per CU
-    int grid = device_cus() * occ;
+    int grid = cus * occ;
     // Work items = tiles x sample chunks.  Large chunks leave the waves finishing at different
     // times at the end of the launch (with 3 chunks per tile that tail was 15 % of a 1024-spp
     // launch); small ones only cost a flush of the tile sums each, since a wave streams from one
@@ -822,22 +863,22 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
 
 hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_depth, const RtDevCamera &cam, RtDevRender rc,
                            uint32_t knobs, float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
-                           RtKernelTimer *timer) {
+                           RtKernelTimer *timer, int cus) {
     if (rc.width == 0 || rc.height == 0 || rc.spp == 0) return hipSuccess;
-    if (workspace_bytes < RT_FUSED_HEADER) return hipErrorInvalidValue;
+    if (workspace_bytes < RT_FUSED_HEADER || rc.band_count == 0 || rc.band_index >= rc.band_count) return hipErrorInvalidValue;
     if (timer) timer->name = "k_fused";
     uint32_t *counter = (uint32_t *)workspace;
     const bool n16 = (knobs & 0x20000u) != 0 && s.nodes16 != nullptr;
-#define RT_FUSED(F, ST, W) (n16 ? fused_launch<F, ST, W, true>(s, cam, rc, accum, counter, knobs, stream, timer) \
-                                : fused_launch<F, ST, W, false>(s, cam, rc, accum, counter, knobs, stream, timer))
+#define RT_FUSED(F, ST, W) (n16 ? fused_launch<F, ST, W, true>(s, cam, rc, accum, counter, knobs, stream, timer, cus) \
+                                : fused_launch<F, ST, W, false>(s, cam, rc, accum, counter, knobs, stream, timer, cus))
     switch (feat & 7u) {
     case 0:
         if (bvh_depth <= 16) return RT_FUSED(0, 16, 8);
         // a deep tree (a million spheres) waits on memory, not on the ALUs: 8 waves per SIMD with
         // the rare deep stack entries in global memory beat 5 waves with the whole stack in LDS
-        if (workspace_bytes >= rt_fused_workspace_bytes())
-            return n16 ? fused_launch<0, 16, 8, true, true>(s, cam, rc, accum, counter, knobs, stream, timer)
-                       : fused_launch<0, 16, 8, false, true>(s, cam, rc, accum, counter, knobs, stream, timer);
+        if (workspace_bytes >= rt_fused_workspace_bytes(cus))
+            return n16 ? fused_launch<0, 16, 8, true, true>(s, cam, rc, accum, counter, knobs, stream, timer, cus)
+                       : fused_launch<0, 16, 8, false, true>(s, cam, rc, accum, counter, knobs, stream, timer, cus);
         return RT_FUSED(0, RT_STACK_DEPTH, 5);
     case 1: return RT_FUSED(1, RT_STACK_DEPTH, 4);
     case 2: return RT_FUSED(2, RT_STACK_DEPTH, 5);

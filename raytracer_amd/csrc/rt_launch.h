@@ -18,29 +18,37 @@ enum : uint32_t {
 };
 
 // HIP events around every launch of the render loop's dominant kernel, on the stream the
-// kernel runs on.  Pairs are kept until collect() sums them (after synchronising).
+// kernel runs on, when timing was asked for (RT_OPTION_KERNEL_TIMING).  Pairs are kept until
+// collect() sums them (after synchronising); the pool is bounded: once RT_TIMER_MAX_EVENTS are
+// in flight the recorded pairs are collected before the next one is taken, so a caller that
+// never reads the time cannot grow it.
+#define RT_TIMER_MAX_EVENTS 512
 struct RtKernelTimer {
     std::vector<hipEvent_t> pool;      // start0, stop0, start1, stop1, ...
     size_t used = 0;
     double total_ms = 0.0;
     uint64_t launches = 0;
     const char *name = "";
-    bool enabled = true;
+    bool enabled = false;
+    bool open = false;                 // begin() recorded a start that end() has to close
 
     void begin(hipStream_t st) {
+        open = false;
         if (!enabled) return;
+        if (used + 2 > RT_TIMER_MAX_EVENTS) collect();
         if (used + 2 > pool.size()) {
             hipEvent_t a, b;
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { enabled = false; return; }
+            if (hipEventCreate(&a) != hipSuccess) { enabled = false; return; }
+            if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); enabled = false; return; }
             pool.push_back(a);
             pool.push_back(b);
         }
-        (void)hipEventRecord(pool[used], st);
+        open = hipEventRecord(pool[used], st) == hipSuccess;
     }
     void end(hipStream_t st) {
-        if (!enabled) return;
-        (void)hipEventRecord(pool[used + 1], st);
-        used += 2;
+        if (!open) return;
+        open = false;
+        if (hipEventRecord(pool[used + 1], st) == hipSuccess) used += 2;
     }
     void collect() {
         for (size_t i = 0; i + 1 < used; i += 2) {
@@ -77,18 +85,22 @@ hipError_t rt_launch_intervals(const RtDevScene &s, uint32_t ref, const float *r
 hipError_t rt_launch_camera_rays(const RtDevCamera &cam, const RtDevRender &rc, int x0, int y0, int w, int h,
                                  float *rays_out, hipStream_t stream);
 hipError_t rt_launch_resolve(const float *accum, float inv_samples, int width, int height, uint8_t *rgbx, hipStream_t stream);
+hipError_t rt_launch_rng_words(const uint32_t *streams, int n, int words_per_stream, uint32_t *out, uint32_t *wyrand_out,
+                               hipStream_t stream);
 
 hipError_t rt_launch_progressive_present(const float *pass_sum, uint32_t spp, uint32_t pass_counter, int width, int height,
                                          uint32_t *acc, uint8_t *bgra, hipStream_t stream);
 
-// spp samples per pixel starting at rc.first_sample, added to accum.
+// spp samples per pixel starting at rc.first_sample, added to accum.  `cus` is the compute-unit
+// count of the device the scene lives on (grids and the deep-stack columns are sized by it).
 hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc,
                                float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
-                               RtKernelTimer *timer);
+                               RtKernelTimer *timer, int cus);
 hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_depth, const RtDevCamera &cam, RtDevRender rc,
                            uint32_t knobs, float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
-                           RtKernelTimer *timer);
+                           RtKernelTimer *timer, int cus);
 
 #define RT_WAVEFRONT_BATCH_SPP 8u      // samples per pixel resident in the path queues at once
 #define RT_FUSED_HEADER 4096u          // the least workspace the fused kernel runs with
-size_t rt_fused_workspace_bytes();      // what it wants: header + deep-stack columns
+size_t rt_fused_workspace_bytes(int cus);      // what it wants: header + deep-stack columns
+int rt_current_device_cus();                    // compute units of the current device (256 if unknown)

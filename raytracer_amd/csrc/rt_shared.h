@@ -35,9 +35,10 @@ enum RtPrimKind : uint32_t {
     RT_KIND_MOTION = 6,
 };
 
-#ifndef RT_STACK_DEPTH
-#define RT_STACK_DEPTH 32        // traversal stack entries per lane (LDS)
-#endif
+// Traversal stack entries per lane (24 KB of LDS per 256-thread workgroup).  The kernels' LDS
+// stacks, the builder's depth limit, the commit-time depth check and the deep-stack columns of
+// the fused workspace all follow this one definition.
+#define RT_STACK_DEPTH 24
 #define RT_BLOCK 256             // threads per workgroup of every traversal kernel
 #define RT_CSG_LEAVES 8
 
@@ -121,6 +122,8 @@ struct RtDevScene {
     const RtDevKitPerlin *kit_perlin;
     uint32_t root;                 // child reference of the root (RT_REF_NONE for an empty scene)
     uint32_t n_nodes;
+    uint32_t kit_convention;       // 1: RayTracingKit's texture coordinates and metal rule (RT_CONVENTION_KIT)
+    uint32_t pad;
 };
 
 // Camera as the kernels use it (Shaders.metal:20-48 computed once on the host instead of
@@ -140,4 +143,7 @@ struct RtDevRender {
     uint32_t first_sample;
     uint32_t seed_lo, seed_hi;
     uint32_t animated;       // 1 when the scene holds moving objects: every sample draws a time after its ray
+    // Image-space sharding: the accumulator holds only the 8-row bands b with b % band_count ==
+    // band_index, stacked; band_count = 1 is the whole image.
+    uint32_t band_index, band_count;
 };

@@ -112,6 +112,9 @@ class NativeScene:
     def set_option(self, option, value):
         check(lib.rt_scene_set_option(self.h, option, value))
 
+    def set_convention(self, convention):
+        self.set_option(abi.RT_OPTION_CONVENTION, convention)
+
     def commit(self):
         check(lib.rt_scene_commit(self.h))
         self.committed = True
@@ -156,12 +159,30 @@ class NativeScene:
         return [evs[i, : cnts[i]] for i in range(n)]
 
 
+def rng_words(ctx, streams, words_per_stream):
+    """Raw PCG32 words of the device's (pixel, sample) streams and the WyRand per-sample seeds.
+    streams: rows of (rng_seed, sample, x, y).  Returns (uint32 [n, words], uint64 [n])."""
+    rec = np.zeros((len(streams), 8), dtype=np.uint32)
+    for i, (seed, sample, x, y) in enumerate(streams):
+        rec[i, :5] = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, sample, x, y)
+    n = len(streams)
+    dev = torch.from_numpy(rec).to(ctx.device)
+    out = torch.zeros((max(n, 1), max(words_per_stream, 1)), dtype=torch.int32, device=ctx.device)
+    wy = torch.zeros((max(n, 1), 2), dtype=torch.int32, device=ctx.device)
+    check(lib.rt_rng_words(ctx.h, dev.data_ptr(), n, words_per_stream, out.data_ptr(), wy.data_ptr(), _stream()))
+    torch.cuda.synchronize(ctx.device)
+    words = out.cpu().numpy().view(np.uint32)[:n, :words_per_stream]
+    w = wy.cpu().numpy().view(np.uint32)[:n].astype(np.uint64)
+    return words, w[:, 0] | (w[:, 1] << np.uint64(32))
+
+
 def camera_rays(ctx, camera, config, width, height, window=None):
     x0, y0, w, h = window if window else (0, 0, width, height)
     n = w * h * config.samples_per_pixel
     out = torch.zeros((max(n, 1), 6), dtype=torch.float32, device=ctx.device)
     cc, rc = camera.impl, config.impl
-    check(lib.rt_camera_rays(ctx.h, C.byref(cc), C.byref(rc), width, height, x0, y0, w, h, out.data_ptr(), _stream()))
+    check(lib.rt_camera_rays(ctx.h, C.byref(cc), C.byref(rc), config.first_sample, width, height, x0, y0, w, h,
+                             out.data_ptr(), _stream()))
     torch.cuda.synchronize(ctx.device)
     return out[:n].cpu().numpy()
 
@@ -171,27 +192,45 @@ class Renderer:
     the float accumulator; the accumulator resets when the size changes (:172-180)."""
 
     def __init__(self, scene, width, height, pipeline=abi.RT_PIPELINE_FUSED, device_ordinal=0, ctx=None, dedup=True,
-                 bvh=abi.RT_BVH_SAH, refill=None, node_min=None, nodes=abi.RT_NODES_AUTO):
-        self.ctx = ctx or Context(device_ordinal)
+                 bvh=abi.RT_BVH_SAH, refill=None, node_min=None, nodes=abi.RT_NODES_AUTO, timing=False, profile_phases=False,
+                 bands=None, native=None):
+        """`native`: an already committed NativeScene of `scene` to render from (a large scene is
+        flattened and its tree built once, then shared by several renderers)."""
+        self.ctx = ctx or (native.ctx if native is not None else Context(device_ordinal))
         self.scene = scene
         self.camera = scene.camera
-        self.native = NativeScene(self.ctx)
-        scene.encode(self.native, dedup=dedup)
-        self.native.set_option(abi.RT_OPTION_BVH_BUILDER, bvh)
-        self.native.set_option(abi.RT_OPTION_NODE_FORMAT, nodes)
+        self.native = native if native is not None else NativeScene(self.ctx)
+        if native is None:
+            scene.encode(self.native, dedup=dedup)
+            self.native.set_option(abi.RT_OPTION_BVH_BUILDER, bvh)
+            self.native.set_option(abi.RT_OPTION_NODE_FORMAT, nodes)
         if refill:
             self.native.set_option(abi.RT_OPTION_REFILL_THRESHOLD, refill)
         if node_min is not None:
             self.native.set_option(abi.RT_OPTION_NODE_MIN, node_min)
-        self.native.commit()
+        if timing:
+            self.native.set_option(abi.RT_OPTION_KERNEL_TIMING, 1)
+        if profile_phases:
+            self.native.set_option(abi.RT_OPTION_PROFILE_PHASES, 1)
+        if native is None:
+            self.native.commit()
         self.pipeline = pipeline
+        # bands = (index, count): this renderer owns every count-th band of 8 pixel rows, starting
+        # at band `index`; its accumulator holds just those bands (image-space sharding)
+        self.bands = bands
+        if bands is not None and pipeline != abi.RT_PIPELINE_FUSED:
+            raise ValueError("image-space sharding runs on the fused pipeline")
         self.pass_counter = 0
         self.samples = 0
         self.resize(width, height)
 
     def resize(self, width, height):
         self.width, self.height = width, height
-        self.accum = torch.zeros((height, width, 3), dtype=torch.float32, device=self.ctx.device)
+        rows = height
+        if self.bands is not None:
+            # every shard's buffer has the rows of shard 0 (the largest), so that equal-sized buffers can be gathered
+            rows = check(lib.rt_band_rows(height, 0, self.bands[1]))
+        self.accum = torch.zeros((rows, width, 3), dtype=torch.float32, device=self.ctx.device)
         ws = lib.rt_render_workspace_size(self.pipeline, width, height)
         self.workspace = torch.empty(max(ws, 256), dtype=torch.uint8, device=self.ctx.device)
         self.pass_counter = 0
@@ -209,8 +248,13 @@ class Renderer:
         first = self.samples if first_sample is None else first_sample
         rc = RenderConfig(samples_per_pixel, max_depth, self.pass_counter, rng_seed, first).impl
         cc = self.camera.impl
-        check(lib.rt_render(self.native.h, C.byref(cc), C.byref(rc), self.pipeline, self.width, self.height,
-                            self.accum.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(), _stream()))
+        if self.bands is None:
+            check(lib.rt_render(self.native.h, C.byref(cc), C.byref(rc), first, self.pipeline, self.width, self.height,
+                                self.accum.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(), _stream()))
+        else:
+            check(lib.rt_render_bands(self.native.h, C.byref(cc), C.byref(rc), first, self.bands[0], self.bands[1],
+                                      self.width, self.height, self.accum.data_ptr(), self.workspace.data_ptr(),
+                                      self.workspace.numel(), _stream()))
         self.samples += samples_per_pixel
 
     def mean(self):
@@ -225,6 +269,7 @@ class Renderer:
         return out[..., :3].cpu().numpy()
 
     def kernel_time(self, reset=False):
+        """(total ms, launches, kernel name) of the dominant kernel since the last reset; needs timing=True."""
         ms, n, name = C.c_double(), C.c_uint64(), C.c_char_p()
         check(lib.rt_kernel_time(self.native.h, 1 if reset else 0, C.byref(ms), C.byref(n), C.byref(name)))
         return ms.value, n.value, (name.value or b"").decode()
@@ -282,7 +327,7 @@ class ProgressiveView:
         r.accum.zero_()
         rc = RenderConfig(self.SAMPLES_PER_PASS, self.MAX_DEPTH, self.pass_counter, seed, 0).impl
         cc = r.camera.impl
-        check(lib.rt_render(r.native.h, C.byref(cc), C.byref(rc), r.pipeline, r.width, r.height, r.accum.data_ptr(),
+        check(lib.rt_render(r.native.h, C.byref(cc), C.byref(rc), 0, r.pipeline, r.width, r.height, r.accum.data_ptr(),
                             r.workspace.data_ptr(), r.workspace.numel(), _stream()))
         check(lib.rt_progressive_present(r.ctx.h, r.accum.data_ptr(), self.SAMPLES_PER_PASS, self.pass_counter,
                                          self.acc.data_ptr(), self.drawable.data_ptr(), r.width, r.height, _stream()))

@@ -106,8 +106,7 @@ class Transform:
         t = abi.RtTransform()
         cols = self.matrix if self.matrix is not None else self.rotation.matrix_columns()
         for c in range(3):
-            for r in range(3):
-                t.rotation[3 * c + r] = float(cols[c][r])
+            t.rotation.columns[c] = _f3(cols[c])
         t.translation = _f3(self.translation)
         return t
 
@@ -216,7 +215,9 @@ class PerlinNoiseTexture:
             t.colors[i] = _f3(self.colors[i])
         t.frequency = self.frequency
         t.turbulence = self.turbulence
-        C.memmove(t.vectors, self.vectors.tobytes(), 256 * 12)
+        padded = np.zeros((256, 4), dtype=np.float32)
+        padded[:, :3] = self.vectors
+        C.memmove(t.vectors, padded.tobytes(), 256 * 16)
         C.memmove(t.permutations, self.permutations.tobytes(), 768)
         return t
 
@@ -242,7 +243,7 @@ class SolidColor(KitTexture):
     def record(self, encoder):
         t = abi.RtKitTexture()
         t.kind = abi.RT_KIT_TEXTURE_SOLID
-        t.color = _f3(self.albedo)
+        t.color = (C.c_float * 3)(*[float(c) for c in self.albedo])
         return t
 
 
@@ -626,11 +627,20 @@ class Quad(Renderable):
                                                   float(d), m))
 
 
+def _csg_operand(shape):
+    """CSG operands and volume bases are primitives or CSG shapes (Impl/RenderableImpl.h:506-523,
+    717-725): a moving or fog-filled operand has no meaning there, and the native library
+    refuses it too."""
+    if isinstance(shape, (MotionBlur, ConstantDensityVolume)):
+        raise TypeError("%s cannot be a CSG operand or a volume base; wrap the whole shape instead" % type(shape).__name__)
+    return shape
+
+
 class Subtract(Renderable):
     """CSG.swift:17-35."""
 
     def __init__(self, lhs, rhs):
-        self.lhs, self.rhs = lhs, rhs
+        self.lhs, self.rhs = _csg_operand(lhs), _csg_operand(rhs)
 
     @property
     def bounding_box(self):
@@ -645,7 +655,7 @@ class Union(Renderable):
     """CSG.swift:53-77."""
 
     def __init__(self, *items):
-        self.items = items
+        self.items = tuple(_csg_operand(it) for it in items)
 
     @property
     def bounding_box(self):
@@ -662,7 +672,7 @@ class Intersection(Renderable):
     """CSG.swift:95-119."""
 
     def __init__(self, *items):
-        self.items = items
+        self.items = tuple(_csg_operand(it) for it in items)
 
     @property
     def bounding_box(self):
@@ -679,7 +689,7 @@ class ConstantDensityVolume(Renderable):
     """ConstantDensityVolume.swift:17-33."""
 
     def __init__(self, base, density):
-        self.base = base
+        self.base = _csg_operand(base)
         self.density = float(density)
 
     @property
@@ -837,19 +847,24 @@ class RenderConfig:
 
     @property
     def impl(self):
-        return abi.RtRenderConfig(self.samples_per_pixel, self.max_depth, self.pass_counter, self.first_sample,
-                                  self.rng_seed)
+        """The reference's record (Config.h:28-33); first_sample travels as an argument."""
+        return abi.RtRenderConfig(self.samples_per_pixel, self.max_depth, self.pass_counter, self.rng_seed)
 
 
 class Scene:
     """Scene.swift:9-16."""
 
-    def __init__(self, camera, objects):
+    def __init__(self, camera, objects, convention=abi.RT_CONVENTION_METAL):
         self.camera = camera
         self.objects = list(objects)
+        # which of the reference's two renderers decides where they disagree (texture coordinates of
+        # spheres and cylinders, the metal absorb rule): scenes of the RayTracingKit CLI use the Kit's
+        self.convention = convention
 
     def encode(self, sink, dedup=True):
         """SceneBuffers.init's loop over objects (SceneBuffers.swift:24-27)."""
+        if self.convention != abi.RT_CONVENTION_METAL:
+            sink.set_convention(self.convention)
         enc = SceneEncoder(sink, dedup=dedup)
         for obj in self.objects:
             sink.add_object(obj.as_impl(enc))

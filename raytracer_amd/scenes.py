@@ -257,7 +257,7 @@ def kit_world1(seed=3, texture_dir=None):
     ]
     cam = CameraConfig(vertical_fov=20, look_from=(-10, 6, 8), look_at=(0, 0, 0), defocus_angle=0.6,
                        focus_distance=10, background=abi.background_lighting_none)
-    return Scene(cam, objs)
+    return Scene(cam, objs, convention=abi.RT_CONVENTION_KIT)
 
 
 def kit_world2(seed=4):
@@ -275,7 +275,7 @@ def kit_world2(seed=4):
         Quad((-2, 6, -2), (4, 0, 0), (0, 0, 4), KitEmissive(CheckerTexture(1.0, (6, 6, 6), (6, 3, 1)))),
     ]
     cam = CameraConfig(vertical_fov=20, look_from=(13, 2, 3), look_at=(0, 0, 0), background=abi.background_lighting_sky)
-    return Scene(cam, objs)
+    return Scene(cam, objs, convention=abi.RT_CONVENTION_KIT)
 
 
 def cornell_smoke():

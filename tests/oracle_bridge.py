@@ -23,6 +23,62 @@ class OrcMaterial(C.Structure):
                 ("refraction_index", C.c_float), ("texture", C.c_uint32)]
 
 
+# The oracle keeps its own packed input records (oracle/oracle_api.h); the records of
+# include/raytracer_amd.h are converted field by field.
+_P3 = C.c_float * 3
+
+
+class OrcTransform(C.Structure):
+    _fields_ = [("rotation", C.c_float * 9), ("translation", _P3)]
+
+
+class OrcSphere(C.Structure):
+    _fields_ = [("transform", OrcTransform), ("radius", C.c_float), ("material_offset", C.c_size_t)]
+
+
+class OrcCylinder(C.Structure):
+    _fields_ = [("transform", OrcTransform), ("radius", C.c_float), ("height", C.c_float),
+                ("bottom_material_offset", C.c_size_t), ("top_material_offset", C.c_size_t),
+                ("side_material_offset", C.c_size_t)]
+
+
+class OrcCuboid(C.Structure):
+    _fields_ = [("transform", OrcTransform), ("size", _P3), ("material_offset", C.c_size_t * 6)]
+
+
+class OrcQuad(C.Structure):
+    _fields_ = [("origin", _P3), ("u", _P3), ("v", _P3), ("w", _P3), ("normal", _P3),
+                ("d", C.c_float), ("material_offset", C.c_size_t)]
+
+
+class OrcPerlin(C.Structure):
+    _fields_ = [("colors", _P3 * 2), ("frequency", C.c_float), ("turbulence", C.c_uint32),
+                ("vectors", _P3 * 256), ("permutations", (C.c_uint8 * 256) * 3)]
+
+
+class OrcCameraConfig(C.Structure):
+    _fields_ = [("vertical_FOV", C.c_float), ("look_from", _P3), ("look_at", _P3), ("up", _P3),
+                ("defocus_angle", C.c_float), ("focus_distance", C.c_float), ("background", C.c_uint32)]
+
+
+def _p3(v):
+    return _P3(v.x, v.y, v.z)
+
+
+def _orc_transform(t):
+    o = OrcTransform()
+    for c in range(3):
+        col = t.rotation.columns[c]
+        o.rotation[3 * c], o.rotation[3 * c + 1], o.rotation[3 * c + 2] = col.x, col.y, col.z
+    o.translation = _p3(t.translation)
+    return o
+
+
+def _orc_camera(cc):
+    return OrcCameraConfig(cc.vertical_FOV, _p3(cc.look_from), _p3(cc.look_at), _p3(cc.up), cc.defocus_angle,
+                           cc.focus_distance, cc.background)
+
+
 class OrcEvent(C.Structure):
     _fields_ = [("t", C.c_double), ("point", C.c_double * 3), ("normal", C.c_double * 3), ("uv", C.c_double * 2),
                 ("material_offset", C.c_uint64), ("is_exit", C.c_int32), ("pad", C.c_int32)]
@@ -105,11 +161,18 @@ class OracleScene:
         k = rec.kind
         if k in (abi.material_kind_lambertian_colored, abi.material_kind_metal_colored,
                  abi.material_kind_emissive_colored, abi.material_kind_isotropic_colored):
-            m.albedo = rec.albedo
+            m.albedo = _p3(rec.albedo)
         if k in (abi.material_kind_lambertian_textured, abi.material_kind_metal_textured):
-            m.texture = rec.albedo.texture_id
+            m.texture = rec.albedo.texture_ptr
         if k in (abi.material_kind_lambertian_perlin_noise, abi.material_kind_metal_perlin_noise):
-            m.texture = _check(self.L.orc_add_perlin(self.h, C.byref(rec.albedo)))
+            src = rec.albedo
+            p = OrcPerlin()
+            p.colors[0], p.colors[1] = _p3(src.colors[0]), _p3(src.colors[1])
+            p.frequency, p.turbulence = src.frequency, src.turbulence
+            vec = np.frombuffer(bytes(src.vectors), dtype=np.float32).reshape(256, 4)[:, :3]
+            C.memmove(p.vectors, np.ascontiguousarray(vec).tobytes(), 256 * 12)
+            C.memmove(p.permutations, bytes(src.permutations), 768)
+            m.texture = _check(self.L.orc_add_perlin(self.h, C.byref(p)))
         if k in (abi.material_kind_metal_colored, abi.material_kind_metal_textured, abi.material_kind_metal_perlin_noise):
             m.fuzz = rec.fuzz
         if k == abi.material_kind_dielectric:
@@ -139,16 +202,21 @@ class OracleScene:
         return np.array(out[:])
 
     def shape_sphere(self, rec):
-        return _check(self.L.orc_shape_sphere(self.h, C.byref(rec)))
+        o = OrcSphere(_orc_transform(rec.transform), rec.radius, rec.material_offset)
+        return _check(self.L.orc_shape_sphere(self.h, C.byref(o)))
 
     def shape_cylinder(self, rec):
-        return _check(self.L.orc_shape_cylinder(self.h, C.byref(rec)))
+        o = OrcCylinder(_orc_transform(rec.transform), rec.radius, rec.height, rec.bottom_material_offset,
+                        rec.top_material_offset, rec.side_material_offset)
+        return _check(self.L.orc_shape_cylinder(self.h, C.byref(o)))
 
     def shape_cuboid(self, rec):
-        return _check(self.L.orc_shape_cuboid(self.h, C.byref(rec)))
+        o = OrcCuboid(_orc_transform(rec.transform), _p3(rec.size), rec.material_offset)
+        return _check(self.L.orc_shape_cuboid(self.h, C.byref(o)))
 
     def shape_quad(self, rec):
-        return _check(self.L.orc_shape_quad(self.h, C.byref(rec)))
+        o = OrcQuad(_p3(rec.origin), _p3(rec.u), _p3(rec.v), _p3(rec.w), _p3(rec.normal), rec.d, rec.material_offset)
+        return _check(self.L.orc_shape_quad(self.h, C.byref(o)))
 
     def shape_csg(self, op, ids):
         arr = (C.c_int * len(ids))(*ids)
@@ -167,6 +235,10 @@ class OracleScene:
         _check(self.L.orc_shape_bounds(self.h, C.c_int(shape), out))
         return np.array(out[:3]), np.array(out[3:])
 
+    def set_convention(self, convention):
+        self.L.orc_set_convention.restype = None
+        self.L.orc_set_convention(self.h, C.c_int(1 if convention == abi.RT_CONVENTION_KIT else 0))
+
     def set_time(self, time):
         self.L.orc_set_query_time.restype = None
         self.L.orc_set_query_time(self.h, C.c_double(time))
@@ -175,13 +247,10 @@ class OracleScene:
         return _check(self.L.orc_add_object(self.h, C.c_int(shape)))
 
     def add_spheres_bulk(self, centers, radii, mat_ids):
-        for c, r, m in zip(centers, radii, mat_ids):
-            rec = abi.RtSphere()
-            rec.transform.rotation = (C.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
-            rec.transform.translation = abi.F3(*[float(v) for v in c])
-            rec.radius = float(r)
-            rec.material_offset = int(m)
-            self.add_object(self.shape_sphere(rec))
+        cr = np.ascontiguousarray(np.concatenate([centers, radii[:, None]], axis=1), dtype=np.float32)
+        m = np.ascontiguousarray(mat_ids, dtype=np.uint32)
+        return _check(self.L.orc_add_sphere_objects(self.h, C.c_int(len(m)), cr.ctypes.data_as(C.c_void_p),
+                                                    m.ctypes.data_as(C.c_void_p)))
 
     def commit(self):
         _check(self.L.orc_commit(self.h))
@@ -217,7 +286,7 @@ class OracleScene:
         if not self.committed:
             self.commit()
         x0, y0, w, h = window if window else (0, 0, width, height)
-        cc = camera.impl
+        cc = _orc_camera(camera.impl)
         rc = OrcRenderConfig(config.samples_per_pixel, config.max_depth, config.first_sample, config.rng_seed)
         out = np.zeros((h, w, 3), dtype=np.float64)
         cnt = OrcCounters()
@@ -230,7 +299,7 @@ class OracleScene:
 
 def camera_rays(camera, config, width, height, window=None, precision=ORC_F32):
     x0, y0, w, h = window if window else (0, 0, width, height)
-    cc = camera.impl
+    cc = _orc_camera(camera.impl)
     rc = OrcRenderConfig(config.samples_per_pixel, config.max_depth, config.first_sample, config.rng_seed)
     out = np.zeros((w * h * config.samples_per_pixel, 6), dtype=np.float64)
     lib().orc_camera_rays(C.byref(cc), C.c_int(precision), C.c_int(width), C.c_int(height), C.byref(rc),
@@ -268,3 +337,26 @@ def progressive_present(pass_sum, samples_per_pixel, pass_counter, acc):
     L.orc_progressive_present(ps.ctypes.data_as(C.c_void_p), C.c_uint32(samples_per_pixel), C.c_uint32(pass_counter),
                               a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_int(len(ps)))
     return a, out
+
+
+def resolve_rgb8(sums, n_samples):
+    """Camera.swift:92 + Vector3D.swift:185-211 in float on the CPU: [n, 3] float32 sums -> [n, 3] uint8."""
+    L = lib()
+    a = np.ascontiguousarray(sums, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros((len(a), 4), dtype=np.uint8)
+    L.orc_resolve_rgb8.restype = None
+    L.orc_resolve_rgb8(a.ctypes.data_as(C.c_void_p), C.c_uint32(n_samples), C.c_int(len(a)), out.ctypes.data_as(C.c_void_p))
+    return out[:, :3]
+
+
+def sample_stream(rng_seed, sample, x, y):
+    """(state, inc) of the PCG32 stream of one (pixel, sample)."""
+    out = (C.c_uint64 * 2)()
+    lib().orc_sample_stream(C.c_uint64(rng_seed), C.c_uint32(sample), C.c_uint32(x), C.c_uint32(y), out)
+    return int(out[0]), int(out[1])
+
+
+def sample_stream_words(rng_seed, sample, x, y, n):
+    out = (C.c_uint32 * n)()
+    lib().orc_sample_stream_words(C.c_uint64(rng_seed), C.c_uint32(sample), C.c_uint32(x), C.c_uint32(y), C.c_int(n), out)
+    return list(out)

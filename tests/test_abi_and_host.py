@@ -22,20 +22,82 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_native.EXPORTS) == declared
     for name in declared:
         assert hasattr(_native.lib, name), name
-    assert _native.lib.rt_abi_version() == 1
+    assert _native.lib.rt_abi_version() == 2
 
 
-def test_record_sizes_match_the_header():
-    # sizes a C compiler gives the header's structs on x86-64
-    assert C.sizeof(abi.RtTransform) == 48
-    assert C.sizeof(abi.RtSphere) == 64
-    assert C.sizeof(abi.RtCylinder) == 80
-    assert C.sizeof(abi.RtCuboid) == 112
-    assert C.sizeof(abi.RtQuad) == 72
-    assert C.sizeof(abi.RtPerlinNoiseTexture) == 24 + 8 + 3072 + 768
-    assert C.sizeof(abi.RtCameraConfig) == 52
+def test_record_sizes_match_the_reference_layout():
+    # sizes of the reference's records with Apple simd types (16-byte vector_float3):
+    # MetalRayTracer/Renderable.h:13-63, Config.h:18-33, Materials.h:38-93
+    assert C.sizeof(abi.RtTransform) == 64
+    assert C.sizeof(abi.RtSphere) == 80
+    assert C.sizeof(abi.RtCylinder) == 96
+    assert C.sizeof(abi.RtCuboid) == 128
+    assert C.sizeof(abi.RtQuad) == 96
+    assert C.sizeof(abi.RtPerlinNoiseTexture) == 4912
+    assert C.sizeof(abi.RtPerlinNoiseLambertianMaterial) == 4928        # the reference's largest material record
+    assert C.sizeof(abi.RtColoredLambertianMaterial) == 32
+    assert C.sizeof(abi.RtCameraConfig) == 80
     assert C.sizeof(abi.RtRenderConfig) == 24
     assert C.sizeof(abi.RtHit) == 48 and C.sizeof(abi.RtEvent) == 48
+
+
+def reference_sphere_bytes(center, radius, material_offset, columns=((1, 0, 0), (0, 1, 0), (0, 0, 1))):
+    """The 80 bytes of the reference's `Sphere` (Renderable.h:13-25) as a Swift host lays them out:
+    three 16-byte rotation columns, a 16-byte translation, radius at 64, material_offset at 72."""
+    import struct
+    b = b"".join(struct.pack("<4f", *col, 0.0) for col in columns)
+    b += struct.pack("<4f", *center, 0.0)
+    b += struct.pack("<f4xQ", radius, material_offset)
+    assert len(b) == 80
+    return b
+
+
+def test_raw_reference_layout_bytes_are_accepted():
+    """A byte image of the reference's records goes through the C ABI as it is (no ctypes record
+    involved), at an odd address too: bounds come back as centre +- radius."""
+    lib, h = _host_scene()
+    mat = bytes([1, 0, 0, 0]) + bytes(12) + np.array([.5, .5, .5, 0], dtype=np.float32).tobytes()   # ColoredLambertianMaterial, 32 bytes
+    assert lib.rt_add_material(h, mat, len(mat)) == 0
+    raw = reference_sphere_bytes((1.0, 2.0, 3.0), 0.5, 0)
+    buf = C.create_string_buffer(b"\0" * 4 + raw)            # 4 bytes off any 16-byte boundary
+    sid = lib.rt_shape_sphere(h, C.cast(C.addressof(buf) + 4, C.POINTER(abi.RtSphere)))
+    assert sid == 0, lib.rt_last_error()
+    out = (C.c_float * 6)()
+    assert lib.rt_shape_bounds(h, sid, out) == 0
+    assert np.allclose(list(out), [0.5, 1.5, 2.5, 1.5, 2.5, 3.5])
+    # the ctypes record is the same bytes
+    rec = abi.RtSphere(abi.RtTransform(abi.RtMatrix3x3(), abi.F3(1, 2, 3)), 0.5, 0)
+    for c in range(3):
+        rec.transform.rotation.columns[c] = abi.F3(*[1.0 if r == c else 0.0 for r in range(3)])
+    assert bytes(rec) == raw
+    lib.rt_scene_destroy(h)
+
+
+def test_moving_shapes_are_refused_as_operands():
+    """CSG leaves and volume bases are tested as plain primitives on the device, so a moving operand
+    is an error at description time, in the library and in the host API."""
+    import pytest
+    from raytracer_amd.scene import (ColoredLambertian, ConstantDensityVolume, MotionBlur, Sphere, Subtract, Union)
+    lib, h = _host_scene()
+    mat = abi.RtColoredLambertianMaterial(abi.material_kind_lambertian_colored, abi.F3(.5, .5, .5))
+    assert lib.rt_add_material(h, C.byref(mat), C.sizeof(mat)) == 0
+    sph = abi.RtSphere(Transform().as_impl, 1.0, 0)
+    a, b, c = (lib.rt_shape_sphere(h, C.byref(sph)) for _ in range(3))
+    motion = abi.RtMotion((C.c_float * 4)(1, 0, 0, 0), (C.c_float * 3)(1, 0, 0))
+    moving = lib.rt_shape_motion(h, a, C.byref(motion))
+    assert moving >= 0
+    two = (C.c_int * 2)(moving, b)
+    assert lib.rt_shape_csg(h, abi.RT_CSG_UNION, 2, two) == -1 and b"moving" in lib.rt_last_error()
+    assert lib.rt_shape_cdv(h, moving, 0.5) == -1 and b"moving" in lib.rt_last_error()
+    lib.rt_scene_destroy(h)
+    m = ColoredLambertian((.5, .5, .5))
+    mb = MotionBlur(Transform.translate(1, 0, 0), Sphere((0, 0, 0), 1, m))
+    with pytest.raises(TypeError):
+        Union(mb, Sphere((0, 0, 0), 1, m))
+    with pytest.raises(TypeError):
+        Subtract(Sphere((0, 0, 0), 1, m), mb)
+    with pytest.raises(TypeError):
+        ConstantDensityVolume(mb, 0.5)
 
 
 def test_error_paths_without_a_gpu():
@@ -129,10 +191,7 @@ def test_description_limits_and_errors_without_a_gpu():
     assert lib.rt_add_material(h, C.byref(bad), C.sizeof(bad)) < 0
     tex = abi.RtTexturedLambertianMaterial(abi.material_kind_lambertian_textured, abi.RtImageTexture(3))
     assert lib.rt_add_material(h, C.byref(tex), C.sizeof(tex)) < 0         # no such texture
-    sph = abi.RtSphere()
-    sph.transform.rotation = (C.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
-    sph.radius = 1.0
-    sph.material_offset = 5
+    sph = abi.RtSphere(Transform().as_impl, 1.0, 5)
     assert lib.rt_shape_sphere(h, C.byref(sph)) < 0 and b"material" in lib.rt_last_error()
     sph.material_offset = 0
     ids = [lib.rt_shape_sphere(h, C.byref(sph)) for _ in range(10)]

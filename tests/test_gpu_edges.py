@@ -86,7 +86,7 @@ def test_axis_parallel_rays_on_every_primitive(ctx):
         rays.append(np.concatenate([o, d], axis=1))
     rays = np.concatenate(rays).astype(np.float32)
     nat, orc = both(ctx, scene)
-    compare_first_hits(nat.first_hit(rays), orc.first_hit(rays), rays, scene, what="axis-parallel", max_bad_frac=1e-3)
+    compare_first_hits(nat.first_hit(rays), orc.first_hit(rays), rays, scene, what="axis-parallel")
 
 
 def test_bvh_builders_give_identical_hits(ctx):

@@ -5,12 +5,12 @@ Bars (stated per test):
     float build of the oracle is held to (the reference's 2^-20 assumes its compiler's
     exact contraction pattern);
   * first hit vs the double-precision oracle: object, material and face identical; t
-    within 1e-5 relative to max(|t|, reach), where reach = distance from the ray origin
-    to the far side of the hit object's bounding sphere.  For objects of the size of
-    their distance this is 1e-5 * t; for a 1000-unit ground sphere seen from 10 units
-    it is the float32 floor (the centre alone carries 6e-5 of rounding).  Rays on
-    which the answer is ill-conditioned (grazing, or two objects within 1e-4) may
-    differ in object; they are counted and bounded.
+    within 1e-5 * |t| and normals within 5e-5 on hits of objects that do not dwarf their
+    distance (compare_first_hits asserts the fraction that meets this, per scene); on a
+    1000-unit ground sphere seen from 10 units the bound is 1e-5 of the object's reach,
+    the float32 floor (the centre alone carries 6e-5 of rounding).  Grazing hits (normal
+    perpendicular to the ray to 0.2 degrees) are ill-conditioned in t and in the side the
+    normal is flipped to; they are counted and bounded.
 """
 import numpy as np
 import pytest
@@ -69,31 +69,62 @@ def bounding_spheres(scene):
     return np.array(c), np.array(r)
 
 
-def compare_first_hits(gpu, ref, rays, scene, rel=1e-5, max_bad_frac=2e-3, what=""):
-    """gpu: HIT_DTYPE array (float32), ref: oracle HIT_DTYPE (float64)."""
-    n = len(rays)
+def classify_first_hits(gpu, ref, rays, scene):
+    """Per-ray error measures of gpu (float32 HIT_DTYPE) against ref (oracle, float64) and the
+    classes the bars are stated on:
+      grazing  the reference normal is within 0.2 degrees of perpendicular to the ray: entry and exit
+               nearly coincide, so t is ill-conditioned and the sign of normal . direction (which
+               way the normal is flipped, and front_face with it) is decided by rounding;
+      big      the hit object reaches more than 32 x |t| from the ray origin (a 1000-unit ground
+               sphere seen from 10 units): float32 places such a hit to 1e-5 of the reach, not of t."""
     same_obj = gpu["object"] == ref["object"]
     both_hit = same_obj & (ref["object"] >= 0)
     o = rays[:, :3].astype(np.float64)
-    # reach: from the ray origin to the far side of the hit object's bounding sphere
+    d = rays[:, 3:].astype(np.float64)
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
     bc, br = bounding_spheres(scene)
     idx = np.maximum(ref["object"], 0)
     reach = np.linalg.norm(o - bc[idx], axis=1) + br[idx]
-    scale = np.maximum(np.abs(ref["t"]), reach)
+    t_ref = np.abs(ref["t"])
     dt = np.abs(gpu["t"].astype(np.float64) - ref["t"])
-    ok_t = dt <= rel * np.maximum(scale, 1e-3)
-    strict = dt <= rel * np.maximum(np.abs(ref["t"]), 1e-3)
     dn = np.max(np.abs(gpu["normal"].astype(np.float64) - ref["normal"]), axis=1)
-    ok_n = dn <= 2e-4
-    ok_id = (gpu["material_offset"] == ref["material_offset"]) & (gpu["front_face"] == ref["front_face"])
-    good = both_hit & ok_t & ok_n & ok_id
-    good |= same_obj & (ref["object"] < 0)
-    bad = int((~good).sum())
-    info = dict(n=n, hits=int(both_hit.sum()), bad=bad, object_mismatch=int((~same_obj).sum()),
-                strict_frac=float(strict[both_hit].mean()) if both_hit.any() else 1.0,
-                max_dt_rel=float((dt[both_hit] / np.maximum(scale[both_hit], 1e-3)).max()) if both_hit.any() else 0.0)
+    grazing = np.abs(np.sum(ref["normal"] * d, axis=1)) < 3.5e-3
+    big = reach > 32.0 * np.maximum(t_ref, 1e-3)
+    ids = (gpu["material_offset"] == ref["material_offset"]) & (gpu["front_face"] == ref["front_face"])
+    return dict(same_obj=same_obj, both_hit=both_hit, reach=reach, t_ref=t_ref, dt=dt, dn=dn, grazing=grazing, big=big, ids=ids)
+
+
+def compare_first_hits(gpu, ref, rays, scene, what="", rel=1e-5, normal_tol=5e-5, strict_frac=0.995, max_bad_frac=1e-3,
+                       max_grazing_frac=5e-3):
+    """The bar of the first-hit comparison, asserted (not printed):
+      * object identical on all but max_bad_frac of the rays (an exact tie between two objects, or
+        a silhouette where one precision hits and the other misses);
+      * on hits that are neither grazing nor on a big object: material and face identical, and at
+        least strict_frac of them have |dt| <= rel * |t| AND normals within normal_tol; the rest
+        are counted in `bad`;
+      * on hits on big objects: |dt| <= rel * reach and normals within normal_tol * reach / |t|;
+      * grazing hits: object only; there may be at most max_grazing_frac of them."""
+    c = classify_first_hits(gpu, ref, rays, scene)
+    n = len(rays)
+    hit, grazing, big = c["both_hit"], c["grazing"], c["big"]
+    plain = hit & ~grazing & ~big
+    large = hit & ~grazing & big
+    ok_plain = (c["dt"] <= rel * np.maximum(c["t_ref"], 1e-3)) & (c["dn"] <= normal_tol) & c["ids"]
+    ok_large = (c["dt"] <= rel * c["reach"]) & (c["dn"] <= normal_tol * c["reach"] / np.maximum(c["t_ref"], 1e-3)) & c["ids"]
+    info = dict(n=n, hits=int(hit.sum()), object_mismatch=int((~c["same_obj"]).sum()),
+                plain=int(plain.sum()), plain_strict_frac=float(ok_plain[plain].mean()) if plain.any() else 1.0,
+                plain_max_dt_rel=float((c["dt"][plain] / np.maximum(c["t_ref"][plain], 1e-3)).max()) if plain.any() else 0.0,
+                plain_p999_dt_rel=float(np.percentile(c["dt"][plain] / np.maximum(c["t_ref"][plain], 1e-3), 99.9)) if plain.any() else 0.0,
+                plain_max_dn=float(c["dn"][plain].max()) if plain.any() else 0.0,
+                plain_id_mismatch=int((~c["ids"][plain]).sum()),
+                large=int(large.sum()), large_ok_frac=float(ok_large[large].mean()) if large.any() else 1.0,
+                large_max_dt_over_reach=float((c["dt"][large] / c["reach"][large]).max()) if large.any() else 0.0,
+                grazing=int((hit & grazing).sum()))
     print(what, info)
-    assert bad <= max(1, int(max_bad_frac * n)), (what, info)
+    assert info["object_mismatch"] <= max(1, int(max_bad_frac * n)), (what, info)
+    assert info["plain_strict_frac"] >= strict_frac, (what, info)
+    assert info["large_ok_frac"] >= strict_frac, (what, info)
+    assert info["grazing"] <= max(2, int(max_grazing_frac * n)), (what, info)
     return info
 
 
@@ -152,7 +183,7 @@ def test_first_hit_cornell_and_quads_volume_boundaries(ctx):
         key = 0x9E3779B97F4A7C15
         g = nat.first_hit(rays, volume_key=key)
         r = orc.first_hit(rays, precision=ob.ORC_F64, volume_key=key)
-        compare_first_hits(g, r, rays, scene, what=name, rel=2e-5)
+        compare_first_hits(g, r, rays, scene, what=name)
 
 
 def test_intervals_csg_random_rays(ctx):

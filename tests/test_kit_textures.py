@@ -279,6 +279,8 @@ def test_kit_world1_with_the_bundled_jpegs():
                     rc = lib.rt_shape_csg(h, args[0], len(args[1]), arr)
                 elif fn == "add_object":
                     rc = lib.rt_add_object(h, args[0])
+                elif fn == "set_convention":
+                    rc = lib.rt_scene_set_option(h, abi.RT_OPTION_CONVENTION, args[0])
                 else:
                     rc = getattr(lib, "rt_" + fn)(h, C.byref(args[0]))
                 assert rc >= 0, (fn, lib.rt_last_error())

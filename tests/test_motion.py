@@ -165,9 +165,8 @@ def test_host_bounds_match_oracle_and_enclose_the_motion():
                 assert (p >= lo - 1e-4).all() and (p <= hi + 1e-4).all(), (name, k)
         # errors: a moving volume, a non-unit quaternion
         bad = abi.RtMotion((C.c_float * 4)(0.5, 0.5, 0, 0), (C.c_float * 3)(0, 0, 0))
-        sph = abi.RtSphere()
-        sph.transform.rotation = (C.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
-        sph.radius = 1.0
+        from raytracer_amd.scene import Transform as _Tr
+        sph = abi.RtSphere(_Tr().as_impl, 1.0, 0)
         mat = abi.RtColoredLambertianMaterial(abi.material_kind_lambertian_colored, abi.F3(.5, .5, .5))
         lib.rt_add_material(h, C.byref(mat), C.sizeof(mat))
         s1 = lib.rt_shape_sphere(h, C.byref(sph))

@@ -1,19 +1,47 @@
-"""Diagnostic: per-phase wave executions, lane occupancy and cycle shares of k_fused
-(run with RT_PROFILE_PHASES=1; the run time of this build is not meaningful)."""
-import os, sys
-os.environ["RT_PROFILE_PHASES"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from raytracer_amd import scenes, abi
-from raytracer_amd.renderer import Renderer
+"""Diagnostic: per-phase wave executions, lane occupancy and cycle shares of k_fused (the
+diagnostic build of the kernel, RT_OPTION_PROFILE_PHASES; its run time is not meaningful).
+
+usage (GPU box): python tools/phase_profile.py <workload> <spp> [executed.json]
+
+For a spheres-only workload the counters also price the work the kernel EXECUTES per sample
+(its own tree, nearest child first): node visits x two box tests + sphere tests + the shading,
+ray generation and accumulation of the algorithmic count.  Written to the third argument as
+the record bench.py quotes beside the algorithmic fraction (profiles/executed_<workload>.json)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from raytracer_amd import roofline, scenes  # noqa: E402
+from raytracer_amd.renderer import Renderer  # noqa: E402
+
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg2_random_spheres_1080p"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 scene, w, h, _, depth, seed = scenes.make_workload(name)
-r = Renderer(scene, w, h)
+r = Renderer(scene, w, h, profile_phases=True)
 r.draw(spp, depth, seed)
 torch.cuda.synchronize()
 pc = r.workspace[256:256 + 96].cpu().numpy().view(np.uint64).reshape(4, 3)
 tot = pc[:, 2].sum()
 for nm, (ex, ln, cy) in zip(["shade", "raygen", "node", "leaf"], pc):
     print("%-7s execs %12d  lanes/exec %5.1f  cycles/exec %7.1f  cycle share %.3f" % (nm, ex, ln / max(ex, 1), cy / max(ex, 1), cy / tot))
-print("samples", w * h * spp)
+samples = w * h * spp
+print("samples", samples)
+print("node visits per sample %.2f  leaf tests per sample %.2f" % (pc[2, 1] / samples, pc[3, 1] / samples))
+st = r.native.stats()
+if len(sys.argv) > 3 and st["n_spheres"] == st["n_objects"]:
+    fixture = os.path.join(ROOT, "tests", "golden", "counters_%s.json" % name)
+    cnt = json.load(open(fixture))["counters"]
+    n = float(cnt["samples"])
+    shade = (sum(cnt["shades"][k] * f for k, f in roofline.F_SHADE.items()) + cnt["hits"] * roofline.F_HIT) / n
+    nodes, leaves = pc[2, 1] / samples, pc[3, 1] / samples
+    executed = roofline.F_RAYGEN + roofline.F_ACCUM + shade + nodes * 2 * roofline.F_BOX + leaves * roofline.F_SPHERE
+    json.dump({"workload": name, "spp": spp, "node_visits_per_sample": nodes, "sphere_tests_per_sample": leaves,
+               "shade_flops_per_sample": shade, "executed_flops_per_sample": executed,
+               "note": "phase counters of the diagnostic k_fused build (tools/phase_profile.py): lanes that took part in node steps "
+                       "and leaf tests; a node visit is two box tests"}, open(sys.argv[3], "w"), indent=1)
+    print("executed flops per sample %.1f" % executed)
