@@ -75,8 +75,9 @@ def classify_first_hits(gpu, ref, rays, scene):
       grazing  the reference normal is within 0.2 degrees of perpendicular to the ray: entry and exit
                nearly coincide, so t is ill-conditioned and the sign of normal . direction (which
                way the normal is flipped, and front_face with it) is decided by rounding;
-      big      the hit object reaches more than 32 x |t| from the ray origin (a 1000-unit ground
-               sphere seen from 10 units): float32 places such a hit to 1e-5 of the reach, not of t."""
+      big      the hit object reaches more than 8 x |t| from the ray origin (a 1000-unit ground
+               sphere seen from 10 units, a 500-unit floor under a demo scene): float32 places such
+               a hit to a few 1e-6 of the reach, not of t (the centre alone carries 6e-5 of rounding)."""
     same_obj = gpu["object"] == ref["object"]
     both_hit = same_obj & (ref["object"] >= 0)
     o = rays[:, :3].astype(np.float64)
@@ -89,20 +90,22 @@ def classify_first_hits(gpu, ref, rays, scene):
     dt = np.abs(gpu["t"].astype(np.float64) - ref["t"])
     dn = np.max(np.abs(gpu["normal"].astype(np.float64) - ref["normal"]), axis=1)
     grazing = np.abs(np.sum(ref["normal"] * d, axis=1)) < 3.5e-3
-    big = reach > 32.0 * np.maximum(t_ref, 1e-3)
+    big = reach > 8.0 * np.maximum(t_ref, 1e-3)
     ids = (gpu["material_offset"] == ref["material_offset"]) & (gpu["front_face"] == ref["front_face"])
     return dict(same_obj=same_obj, both_hit=both_hit, reach=reach, t_ref=t_ref, dt=dt, dn=dn, grazing=grazing, big=big, ids=ids)
 
 
-def compare_first_hits(gpu, ref, rays, scene, what="", rel=1e-5, normal_tol=5e-5, strict_frac=0.995, max_bad_frac=1e-3,
+def compare_first_hits(gpu, ref, rays, scene, what="", rel=1e-5, normal_tol=5e-5, strict_frac=0.999, max_bad_frac=1e-3,
                        max_grazing_frac=5e-3):
     """The bar of the first-hit comparison, asserted (not printed):
       * object identical on all but max_bad_frac of the rays (an exact tie between two objects, or
         a silhouette where one precision hits and the other misses);
-      * on hits that are neither grazing nor on a big object: material and face identical, and at
-        least strict_frac of them have |dt| <= rel * |t| AND normals within normal_tol; the rest
-        are counted in `bad`;
-      * on hits on big objects: |dt| <= rel * reach and normals within normal_tol * reach / |t|;
+      * on hits that are neither grazing nor on a big object: at least strict_frac of them have
+        material and face identical, |dt| <= 1e-5 * |t| AND normals within 5e-5 (measured on
+        MI355X over every scene of the tests: all of them, largest |dt| / |t| 4.1e-6, largest normal
+        difference 4.3e-5);
+      * on hits on big objects: the same with |dt| <= 1e-5 * reach (measured: at most 3.7e-6 * reach,
+        at the horizon of the 1000-unit ground sphere);
       * grazing hits: object only; there may be at most max_grazing_frac of them."""
     c = classify_first_hits(gpu, ref, rays, scene)
     n = len(rays)
@@ -110,7 +113,7 @@ def compare_first_hits(gpu, ref, rays, scene, what="", rel=1e-5, normal_tol=5e-5
     plain = hit & ~grazing & ~big
     large = hit & ~grazing & big
     ok_plain = (c["dt"] <= rel * np.maximum(c["t_ref"], 1e-3)) & (c["dn"] <= normal_tol) & c["ids"]
-    ok_large = (c["dt"] <= rel * c["reach"]) & (c["dn"] <= normal_tol * c["reach"] / np.maximum(c["t_ref"], 1e-3)) & c["ids"]
+    ok_large = (c["dt"] <= rel * c["reach"]) & (c["dn"] <= normal_tol) & c["ids"]
     info = dict(n=n, hits=int(hit.sum()), object_mismatch=int((~c["same_obj"]).sum()),
                 plain=int(plain.sum()), plain_strict_frac=float(ok_plain[plain].mean()) if plain.any() else 1.0,
                 plain_max_dt_rel=float((c["dt"][plain] / np.maximum(c["t_ref"][plain], 1e-3)).max()) if plain.any() else 0.0,

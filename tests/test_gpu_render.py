@@ -3,11 +3,13 @@ double-precision CPU oracle on the same scene, seed and sample indices (GPU need
 
 Both renderers draw sample s of pixel (x, y) from the same generator stream, so most
 paths are the same path; the few that diverge (a float32 rounding flips a branch) are
-independent samples of the same estimator.  Bars: PSNR of the mean image >= 30 dB at the
-tested sample counts and relative difference of the image-wide mean <= 2 %; the two
-pipelines must agree with each other far more tightly (they are the same float32 code
-in a different schedule: PSNR >= 60 dB, differences only from the order of float adds
-and from paths whose volume draws see a different generator state word).
+independent samples of the same estimator.  Every material kind's scatter rule is in
+these paths (a wrong Schlick exponent or reflection rule changes most pixels of its
+scene), so the bars are the measured values less a margin, per scene: PSNR of the mean
+image, the fraction of pixels equal to 1e-3, and the relative difference of the image-wide
+mean.  The two pipelines must agree with each other far more tightly (they are the same
+float32 code in a different schedule: PSNR >= 60 dB, differences only from the order of
+float adds and from paths whose volume draws see a different generator state word).
 """
 import numpy as np
 import pytest
@@ -43,6 +45,11 @@ CASES = [
     ("quads", lambda: scenes.quads(9), 96, 64, 32, 10, 9),
     ("world1", lambda: scenes.world1(21), 120, 68, 32, 50, 21),
 ]
+# (PSNR dB, fraction of pixels equal to 1e-3, relative difference of the image mean); measured on MI355X:
+# random_spheres 59.7 / 0.987 / 1e-4, cornell_smoke 64.0 / 0.997 / 2e-4, csg_textured 59.0 / 0.995 / 1e-4,
+# quads 111.7 / 1.000 / 0, world1 45.5 / 0.919 / 8e-3 (a defocused camera and a small light: few, bright paths)
+BARS = {"random_spheres": (55.0, 0.97, 2e-3), "cornell_smoke": (58.0, 0.99, 2e-3), "csg_textured": (54.0, 0.98, 2e-3),
+        "quads": (90.0, 0.999, 1e-4), "world1": (41.0, 0.89, 2e-2)}
 
 
 @pytest.mark.parametrize("name,make,w,h,spp,depth,seed", CASES, ids=[c[0] for c in CASES])
@@ -58,8 +65,10 @@ def test_mean_radiance_matches_oracle(name, make, w, h, spp, depth, seed):
         rel = abs(got.mean() - ref.mean()) / max(ref.mean(), 1e-9)
         same = np.mean(np.max(np.abs(got - ref), axis=2) <= 1e-3 * np.maximum(1.0, np.max(ref, axis=2)))
         print(name, "pipeline", pipeline, "PSNR %.1f dB" % p, "mean rel %.4f" % rel, "pixels equal to 1e-3: %.3f" % same)
-        assert p >= 30.0, (name, pipeline, p)
-        assert rel <= 0.02, (name, pipeline, rel)
+        need_db, need_same, need_rel = BARS[name]
+        assert p >= need_db, (name, pipeline, p)
+        assert same >= need_same, (name, pipeline, same)
+        assert rel <= need_rel, (name, pipeline, rel)
 
 
 @pytest.mark.parametrize("name,make,w,h,spp,depth,seed", CASES[:3], ids=[c[0] for c in CASES[:3]])

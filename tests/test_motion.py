@@ -231,7 +231,9 @@ def test_first_hits_of_a_moving_scene(ctx, time):
     orc.set_time(time)
     rays = np.concatenate([camera_rays(ctx, scene.camera, RenderConfig(1, 1, 1, 5, 0), 160, 90),
                            random_rays(6000, 8, center=(0, 0.5, 0), radius=9.0, aim_radius=6.0)]).astype(np.float32)
-    compare_first_hits(nat.first_hit(rays), orc.first_hit(rays), rays, scene, what="bouncing t=%.2f" % time)
+    # a moving sphere's normal goes through the frame of transform.pow(t): float sinf / cosf of the
+    # half angle add to the 0.2-unit spheres' own floor (measured: at most 9.9e-5)
+    compare_first_hits(nat.first_hit(rays), orc.first_hit(rays), rays, scene, what="bouncing t=%.2f" % time, normal_tol=2e-4)
     assert nat.stats()["n_objects"] == len(scene.objects)
 
 
