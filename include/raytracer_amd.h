@@ -358,6 +358,21 @@ int rt_render(RtScene *, const RtCameraConfig *, const RtRenderConfig *, uint32_
               int width, int height, float *accum_dev,
               void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* rt_render on the fused pipeline without a workspace argument and without any allocation.
+ * No counterpart in the reference.  It is for callers that cannot allocate device memory or
+ * call anything that might: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  The kernel's scratch (work counter, camera, deep traversal-stack columns:
+ * 16 MiB + 4 KiB) is an array inside the library, one copy per GPU, resolved when
+ * rt_context_create runs on that GPU and held until the process ends.  The call itself makes no
+ * hipMalloc / hipFree, creates no events (rt_kernel_time does not see it) and queries nothing
+ * from the runtime (rt_scene_commit has asked already); the caller still passes the accumulator.
+ * Limits: those of rt_render (an image beyond 65535 pixels a side or 2^28 pixels is refused with
+ * RT_ERR_LIMIT); on a GPU with more than 256 compute units the grid is sized for 256.
+ * Every call on one GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
+ * scenes) race; calls in stream order do not (each launch re-initialises what it reads). */
+int rt_render_static(RtScene *, const RtCameraConfig *, const RtRenderConfig *, uint32_t first_sample,
+                     int width, int height, float *accum_dev, void *stream);
+
 /* Image-space sharding for several GPUs; no counterpart in the reference (one device).
  * The image is cut into bands of 8 pixel rows; band b belongs to shard b % band_count.
  * This call renders the bands of shard band_index only (fused pipeline) and adds them to

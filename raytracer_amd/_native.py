@@ -17,7 +17,7 @@ EXPORTS = [
     "rt_shape_motion", "rt_shape_bounds", "rt_scene_set_time",
     "rt_add_object", "rt_add_sphere_objects", "rt_scene_commit", "rt_scene_stats", "rt_scene_set_option",
     "rt_first_hit", "rt_intervals", "rt_camera_rays", "rt_rng_words",
-    "rt_render_workspace_size", "rt_render", "rt_band_rows", "rt_render_bands", "rt_resolve_rgb8", "rt_progressive_present",
+    "rt_render_workspace_size", "rt_render", "rt_render_static", "rt_band_rows", "rt_render_bands", "rt_resolve_rgb8", "rt_progressive_present",
     "rt_kernel_time",
 ]
 
@@ -69,6 +69,7 @@ def _load():
         "rt_render_workspace_size": (C.c_size_t, [i32, i32, i32]),
         "rt_render": (i32, [vp, C.POINTER(abi.RtCameraConfig), C.POINTER(abi.RtRenderConfig), u32, i32, i32, i32, vp, vp,
                             C.c_size_t, vp]),
+        "rt_render_static": (i32, [vp, C.POINTER(abi.RtCameraConfig), C.POINTER(abi.RtRenderConfig), u32, i32, i32, vp, vp]),
         "rt_band_rows": (i32, [i32, i32, i32]),
         "rt_render_bands": (i32, [vp, C.POINTER(abi.RtCameraConfig), C.POINTER(abi.RtRenderConfig), u32, i32, i32, i32, i32,
                                   vp, vp, C.c_size_t, vp]),

@@ -546,6 +546,9 @@ int rt_context_create(int device_ordinal, RtContext **out) {
     if (device_ordinal < 0 || device_ordinal >= n) return fail(RT_ERR_INVALID, "no such device");
     e = hipSetDevice(device_ordinal);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    // the address of this device's copy of the library's scratch array (rt_render_static)
+    e = rt_static_scratch_init(device_ordinal);
+    if (e != hipSuccess) return fail_hip(e, "hipGetSymbolAddress of the static scratch");
     RtContext *c = new RtContext();
     c->device = device_ordinal;
     (void)hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device_ordinal);
@@ -1119,6 +1122,14 @@ int rt_scene_commit(RtScene *sc) {
     st.n_textures = (uint32_t)sc->textures.size();
     st.n_perlin = (uint32_t)sc->perlin.size();
     sc->committed = true;
+    {
+        // ask now what a render call of this scene would ask the runtime, so that rendering queries nothing
+        RtDevCamera cam{};
+        RtDevRender r{};
+        r.band_count = 1;
+        (void)rt_render_fused(sc->dev, sc->feat, st.bvh_depth, cam, r, sc->use_nodes16 ? 0x20000u : 0u, nullptr, nullptr, 0, nullptr,
+                              nullptr, sc->ctx->cus, true);
+    }
     return RT_OK;
 }
 
@@ -1275,6 +1286,23 @@ int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, u
     } else {
         return fail(RT_ERR_INVALID, "unknown pipeline");
     }
+    return e == hipSuccess ? RT_OK : fail_hip(e, "render");
+}
+
+int rt_render_static(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, uint32_t first_sample, int width, int height,
+                     float *accum_dev, void *stream) {
+    int chk = render_checks(sc, cc, rc, accum_dev, width, height);
+    if (chk < 0) return chk;
+    DeviceScope on_device(sc->ctx->device);
+    if (!on_device.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
+    RtDevCamera cam;
+    make_camera(copy_record(cc), width, height, cam);
+    RtDevRender r = make_render(copy_record(rc), first_sample, width, height);
+    r.animated = (sc->feat & RT_FEAT_MOTION) ? 1u : 0u;
+    // the diagnostic build reports through a workspace the caller can read: not on this path
+    const uint32_t knobs = fused_knobs(sc, cam) & ~0x10000u;
+    hipError_t e = rt_render_fused_static(sc->dev, sc->feat, sc->stats.bvh_depth, cam, r, knobs, accum_dev, as_stream(stream),
+                                          sc->ctx->cus, sc->ctx->device);
     return e == hipSuccess ? RT_OK : fail_hip(e, "render");
 }
 

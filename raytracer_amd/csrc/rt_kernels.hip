@@ -817,13 +817,15 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
 
 template <int FEAT, int STACK, int WPS, bool NODE16, bool DEEP = false>
 static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, const RtDevRender &rc, float *accum,
-                               uint32_t *counter, uint32_t knobs, hipStream_t stream, RtKernelTimer *timer, int cus) {
+                               uint32_t *counter, uint32_t knobs, hipStream_t stream, RtKernelTimer *timer, int cus,
+                               bool prepare_only) {
     // tile rows of this shard (all of them when band_count is 1)
     const uint32_t all_rows = (rc.height + 7u) / 8u;
     const uint32_t tiles_y = rc.band_index < all_rows ? (all_rows - rc.band_index + rc.band_count - 1u) / rc.band_count : 0u;
     const uint32_t tiles_x = (rc.width + 7u) / 8u, n_tiles = tiles_x * tiles_y;
-    if (n_tiles == 0) return hipSuccess;
-    // workgroups per compute unit of this instantiation: asked once per device
+    if (n_tiles == 0 && !prepare_only) return hipSuccess;
+    // workgroups per compute unit of this instantiation: asked once per device (at commit, so
+    // that a render call makes no runtime query)
     static int occ_of_device[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -832,6 +834,7 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS, NODE16, DEEP>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
         if (dev >= 0 && dev < 64) occ_of_device[dev] = occ;
     }
+    if (prepare_only) return hipSuccess;
     if (DEEP) occ = std::min(occ, 8);        // the deep-stack columns are sized for 8 workgroups per CU
     int grid = cus * occ;
     // Work items = tiles x sample chunks.  Large chunks leave the waves finishing at different
@@ -863,22 +866,26 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
 
 hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_depth, const RtDevCamera &cam, RtDevRender rc,
                            uint32_t knobs, float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
-                           RtKernelTimer *timer, int cus) {
-    if (rc.width == 0 || rc.height == 0 || rc.spp == 0) return hipSuccess;
-    if (workspace_bytes < RT_FUSED_HEADER || rc.band_count == 0 || rc.band_index >= rc.band_count) return hipErrorInvalidValue;
+                           RtKernelTimer *timer, int cus, bool prepare_only) {
+    if (!prepare_only) {
+        if (rc.width == 0 || rc.height == 0 || rc.spp == 0) return hipSuccess;
+        if (workspace_bytes < RT_FUSED_HEADER || rc.band_count == 0 || rc.band_index >= rc.band_count) return hipErrorInvalidValue;
+    }
     if (timer) timer->name = "k_fused";
     uint32_t *counter = (uint32_t *)workspace;
     const bool n16 = (knobs & 0x20000u) != 0 && s.nodes16 != nullptr;
-#define RT_FUSED(F, ST, W) (n16 ? fused_launch<F, ST, W, true>(s, cam, rc, accum, counter, knobs, stream, timer, cus) \
-                                : fused_launch<F, ST, W, false>(s, cam, rc, accum, counter, knobs, stream, timer, cus))
+#define RT_FUSED(F, ST, W) (n16 ? fused_launch<F, ST, W, true>(s, cam, rc, accum, counter, knobs, stream, timer, cus, prepare_only) \
+                                : fused_launch<F, ST, W, false>(s, cam, rc, accum, counter, knobs, stream, timer, cus, prepare_only))
     switch (feat & 7u) {
     case 0:
         if (bvh_depth <= 16) return RT_FUSED(0, 16, 8);
         // a deep tree (a million spheres) waits on memory, not on the ALUs: 8 waves per SIMD with
         // the rare deep stack entries in global memory beat 5 waves with the whole stack in LDS
-        if (workspace_bytes >= rt_fused_workspace_bytes(cus))
-            return n16 ? fused_launch<0, 16, 8, true, true>(s, cam, rc, accum, counter, knobs, stream, timer, cus)
-                       : fused_launch<0, 16, 8, false, true>(s, cam, rc, accum, counter, knobs, stream, timer, cus);
+        if (workspace_bytes >= rt_fused_workspace_bytes(cus) || prepare_only) {
+            hipError_t e = n16 ? fused_launch<0, 16, 8, true, true>(s, cam, rc, accum, counter, knobs, stream, timer, cus, prepare_only)
+                               : fused_launch<0, 16, 8, false, true>(s, cam, rc, accum, counter, knobs, stream, timer, cus, prepare_only);
+            if (!prepare_only) return e;
+        }
         return RT_FUSED(0, RT_STACK_DEPTH, 5);
     case 1: return RT_FUSED(1, RT_STACK_DEPTH, 4);
     case 2: return RT_FUSED(2, RT_STACK_DEPTH, 5);
@@ -887,4 +894,33 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
     default: return RT_FUSED(7, RT_STACK_DEPTH, 4);
     }
 #undef RT_FUSED
+}
+
+// ------------------------------------------------------------------ render without a workspace argument
+// The fused kernel's scratch (work counter, diagnostics, camera, deep-stack columns) for callers
+// that cannot allocate device memory: one array per GPU, part of the loaded code object, held
+// until the process ends.  `scratch` is a host-side stand-in for the symbol, never a device
+// address: the address of each device's copy comes from hipGetSymbolAddress with that device
+// current (rt_static_scratch_init), and only that pointer is handed to kernels and memsets.
+#define RT_STATIC_SCRATCH_BYTES (RT_FUSED_DEEP_OFFSET + (size_t)RT_STATIC_MAX_CUS * 8u * RT_BLOCK * (RT_STACK_DEPTH - 16) * 4u)
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+static void *scratch_of_device[RT_STATIC_MAX_DEVICES];
+
+hipError_t rt_static_scratch_init(int device) {
+    if (device < 0 || device >= RT_STATIC_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (scratch_of_device[device]) return hipSuccess;
+    void *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!ptr) return hipErrorInvalidSymbol;
+    scratch_of_device[device] = ptr;
+    return hipSuccess;
+}
+
+hipError_t rt_render_fused_static(const RtDevScene &s, uint32_t feat, uint32_t bvh_depth, const RtDevCamera &cam, RtDevRender rc,
+                                  uint32_t knobs, float *accum, hipStream_t stream, int cus, int device) {
+    if (device < 0 || device >= RT_STATIC_MAX_DEVICES || !scratch_of_device[device]) return hipErrorNotInitialized;
+    // a device with more compute units than the columns were sized for runs the grid of RT_STATIC_MAX_CUS units
+    return rt_render_fused(s, feat, bvh_depth, cam, rc, knobs, accum, scratch_of_device[device], RT_STATIC_SCRATCH_BYTES, stream,
+                           nullptr, std::min(cus, RT_STATIC_MAX_CUS), false);
 }
