@@ -326,6 +326,30 @@ int rt_intervals(RtScene *, int shape, const float *rays_dev, int n,
                  const float *scripted_u_dev, int n_scripted, uint64_t volume_key,
                  RtEvent *events_dev, int32_t *counts_dev, void *stream);
 
+/* One scattering event of a material at a given hit (MaterialsImpl.h:147-215; under
+ * RT_CONVENTION_KIT the metal rule of RayTracingKit/Material.swift:53-57), with the random
+ * numbers of the generator stream of (rng_seed, rng_sample, rng_x, rng_y): what the shade stage
+ * does to one path, exposed so that every material kind can be compared with a host
+ * implementation draw for draw.  queries_dev / out_dev: n records. */
+typedef struct {
+    float direction[3];       /* incoming ray direction (unit) */
+    float normal[3];          /* hit normal, already flipped to oppose the ray */
+    float point[3];
+    float uv[2];
+    int32_t front_face;
+    uint32_t material_offset;
+    uint32_t rng_sample, rng_x, rng_y;
+} RtScatterQuery;
+typedef struct {
+    int32_t scattered;        /* 0: the path ends here (emissive, or absorbed) */
+    float direction[3];       /* outgoing direction when scattered */
+    float attenuation[3];
+    float emitted[3];
+    uint32_t pad[2];
+} RtScatterResult;
+int rt_scatter(RtScene *, const RtScatterQuery *queries_dev, int n, uint64_t rng_seed,
+               RtScatterResult *out_dev, void *stream);
+
 /* The ray-generation stage alone (Shaders.metal:30-67): rays of samples
  * first_sample .. first_sample+samples_per_pixel-1 of the pixels of the window
  * [x0,x0+w) x [y0,y0+h), pixel-major then sample; out n x 6 floats. */

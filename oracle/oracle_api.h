@@ -192,6 +192,21 @@ int orc_enumerate(const OrcScene *, int shape, int precision,
 int orc_first_hit(const OrcScene *, int precision, int n, const double *rays,
                   double tmin, double tmax, uint64_t cdv_state, OrcHit *out);
 
+/* One scattering event of a material at a given hit (MaterialsImpl.h:147-215 / Material.swift),
+ * drawing from the generator stream of (rng_seed, sample, x, y). */
+typedef struct {
+    double direction[3], normal[3], point[3], uv[2];
+    int32_t front_face;
+    uint32_t material_offset;
+    uint32_t sample, x, y;
+    uint32_t pad;
+} OrcScatterQuery;
+typedef struct {
+    int32_t scattered, pad;
+    double direction[3], attenuation[3], emitted[3];
+} OrcScatterResult;
+int orc_scatter(const OrcScene *, int precision, int n, const OrcScatterQuery *queries, uint64_t rng_seed, OrcScatterResult *out);
+
 /* Camera rays as the renderer generates them: out = n*6 doubles. */
 int orc_camera_rays(const OrcCameraConfig *, int precision, int width, int height,
                     const OrcRenderConfig *, int x0, int y0, int w, int h, double *out);

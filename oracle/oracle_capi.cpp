@@ -228,6 +228,39 @@ int orc_first_hit(const OrcScene *s, int precision, int n, const double *rays, d
 }
 
 template <class R>
+static void scatter_t(const Scene &sc, int n, const OrcScatterQuery *queries, uint64_t seed, OrcScatterResult *out) {
+    for (int i = 0; i < n; i++) {
+        const OrcScatterQuery &q = queries[i];
+        HitInfo<R> hit;
+        hit.point = V3<R>(R(q.point[0]), R(q.point[1]), R(q.point[2]));
+        hit.normal = V3<R>(R(q.normal[0]), R(q.normal[1]), R(q.normal[2]));
+        hit.front = q.front_face != 0;
+        hit.material_offset = q.material_offset;
+        hit.u = R(q.uv[0]); hit.v = R(q.uv[1]);
+        Ray<R> ray{hit.point, V3<R>(R(q.direction[0]), R(q.direction[1]), R(q.direction[2]))};
+        Rng rng;
+        rng.pcg = sample_stream(seed, q.sample, q.x, q.y);
+        ScatterResult<R> res;
+        res.scattered = ray;
+        bool did = scatter<R>(sc, sc.materials[q.material_offset], ray, hit, rng, res);
+        OrcScatterResult &o = out[i];
+        std::memset(&o, 0, sizeof(o));
+        o.scattered = did ? 1 : 0;
+        if (did) { o.direction[0] = res.scattered.direction.x; o.direction[1] = res.scattered.direction.y; o.direction[2] = res.scattered.direction.z; }
+        o.attenuation[0] = res.attenuation.x; o.attenuation[1] = res.attenuation.y; o.attenuation[2] = res.attenuation.z;
+        o.emitted[0] = res.emitted.x; o.emitted[1] = res.emitted.y; o.emitted[2] = res.emitted.z;
+    }
+}
+
+int orc_scatter(const OrcScene *s, int precision, int n, const OrcScatterQuery *queries, uint64_t rng_seed, OrcScatterResult *out) {
+    for (int i = 0; i < n; i++)
+        if (queries[i].material_offset >= s->s.materials.size()) return fail("bad material offset");
+    if (precision == ORC_F32) scatter_t<float>(s->s, n, queries, rng_seed, out);
+    else scatter_t<double>(s->s, n, queries, rng_seed, out);
+    return 0;
+}
+
+template <class R>
 static void camera_rays_t(const OrcCameraConfig *cc, int width, int height, const OrcRenderConfig *rc,
                           int x0, int y0, int w, int h, double *out) {
     Camera<R> cam(width, height, *cc);

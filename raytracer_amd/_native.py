@@ -16,7 +16,7 @@ EXPORTS = [
     "rt_shape_sphere", "rt_shape_cylinder", "rt_shape_cuboid", "rt_shape_quad", "rt_shape_csg", "rt_shape_cdv",
     "rt_shape_motion", "rt_shape_bounds", "rt_scene_set_time",
     "rt_add_object", "rt_add_sphere_objects", "rt_scene_commit", "rt_scene_stats", "rt_scene_set_option",
-    "rt_first_hit", "rt_intervals", "rt_camera_rays", "rt_rng_words",
+    "rt_first_hit", "rt_intervals", "rt_scatter", "rt_camera_rays", "rt_rng_words",
     "rt_render_workspace_size", "rt_render", "rt_render_static", "rt_band_rows", "rt_render_bands", "rt_resolve_rgb8", "rt_progressive_present",
     "rt_kernel_time",
 ]
@@ -66,6 +66,7 @@ def _load():
         "rt_camera_rays": (i32, [vp, C.POINTER(abi.RtCameraConfig), C.POINTER(abi.RtRenderConfig), u32, i32, i32, i32, i32,
                                  i32, i32, vp, vp]),
         "rt_rng_words": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+        "rt_scatter": (i32, [vp, vp, i32, u64, vp, vp]),
         "rt_render_workspace_size": (C.c_size_t, [i32, i32, i32]),
         "rt_render": (i32, [vp, C.POINTER(abi.RtCameraConfig), C.POINTER(abi.RtRenderConfig), u32, i32, i32, i32, vp, vp,
                             C.c_size_t, vp]),

@@ -44,6 +44,7 @@ static_assert(sizeof(RtColoredMetalMaterial) == 48 && offsetof(RtColoredMetalMat
 static_assert(sizeof(RtTexturedMetalMaterial) == 24 && offsetof(RtTexturedMetalMaterial, fuzz) == 16, "TexturedMetalMaterial");
 static_assert(sizeof(RtPerlinNoiseMetalMaterial) == 4944 && offsetof(RtPerlinNoiseMetalMaterial, fuzz) == 4928, "PerlinNoiseMetalMaterial");
 static_assert(sizeof(RtDielectricMaterial) == 8, "DielectricMaterial");
+static_assert(sizeof(RtScatterQuery) == 64 && sizeof(RtScatterResult) == 48, "scatter records");
 
 namespace {
 
@@ -1214,6 +1215,16 @@ int rt_camera_rays(RtContext *ctx, const RtCameraConfig *cc, const RtRenderConfi
     RtDevRender r = make_render(copy_record(rc), first_sample, width, height);
     hipError_t e = rt_launch_camera_rays(cam, r, x0, y0, w, h, rays_out_dev, as_stream(stream));
     return e == hipSuccess ? RT_OK : fail_hip(e, "camera-rays launch");
+}
+
+int rt_scatter(RtScene *sc, const RtScatterQuery *queries_dev, int n, uint64_t rng_seed, RtScatterResult *out_dev, void *stream) {
+    if (!sc || n < 0 || (n > 0 && (!queries_dev || !out_dev))) return fail(RT_ERR_INVALID, "bad argument");
+    if (!sc->committed) return fail(RT_ERR_STATE, "scene not committed");
+    if (sc->material_kinds.empty()) return fail(RT_ERR_STATE, "scene has no materials");
+    DeviceScope on_device(sc->ctx->device);
+    if (!on_device.ok) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
+    hipError_t e = rt_launch_scatter(sc->dev, queries_dev, n, rng_seed, out_dev, as_stream(stream));
+    return e == hipSuccess ? RT_OK : fail_hip(e, "scatter launch");
 }
 
 int rt_rng_words(RtContext *ctx, const uint32_t *streams_dev, int n, int words_per_stream, uint32_t *out_dev,

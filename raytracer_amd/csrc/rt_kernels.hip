@@ -212,6 +212,32 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float *accum, float 
     ((uint32_t *)rgbx)[i] = px;
 }
 
+// One scattering event per query: the shade stage's material step alone.
+__global__ __launch_bounds__(RT_BLOCK) void k_scatter(RtDevScene s, const RtScatterQuery *queries, int n, uint64_t seed,
+                                                       RtScatterResult *out) {
+    int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const RtScatterQuery q = queries[i];
+    HitRecord h;
+    h.point = ld3(q.point);
+    h.normal = ld3(q.normal);
+    h.u = q.uv[0]; h.v = q.uv[1];
+    h.material = q.material_offset;
+    h.object = 0;
+    h.front = q.front_face != 0;
+    Material m = load_material(s, q.material_offset);
+    Pcg g = sample_stream(seed, q.rng_sample, q.rng_x, q.rng_y);
+    f3 emitted, atten, nd = mk3(0, 0, 0);
+    bool did = scatter<true>(s, m, ld3(q.direction), h, g, emitted, atten, nd);
+    RtScatterResult r;
+    r.scattered = did ? 1 : 0;
+    r.direction[0] = nd.x; r.direction[1] = nd.y; r.direction[2] = nd.z;
+    r.attenuation[0] = atten.x; r.attenuation[1] = atten.y; r.attenuation[2] = atten.z;
+    r.emitted[0] = emitted.x; r.emitted[1] = emitted.y; r.emitted[2] = emitted.z;
+    r.pad[0] = r.pad[1] = 0;
+    out[i] = r;
+}
+
 // Raw generator words for bit-exact comparison with a host implementation.
 __global__ __launch_bounds__(RT_BLOCK) void k_rng_words(const uint32_t *streams, int n, int words, uint32_t *out, uint32_t *wy_out) {
     int i = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -723,6 +749,13 @@ hipError_t rt_launch_resolve(const float *accum, float n_samples, int width, int
     int npix = width * height;
     if (npix <= 0) return hipSuccess;
     k_resolve<<<blocks_for(npix), RT_BLOCK, 0, stream>>>(accum, n_samples, npix, rgbx);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_scatter(const RtDevScene &s, const RtScatterQuery *queries, int n, uint64_t seed, RtScatterResult *out,
+                             hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    k_scatter<<<blocks_for(n), RT_BLOCK, 0, stream>>>(s, queries, n, seed, out);
     return hipGetLastError();
 }
 

@@ -85,6 +85,8 @@ hipError_t rt_launch_intervals(const RtDevScene &s, uint32_t ref, const float *r
 hipError_t rt_launch_camera_rays(const RtDevCamera &cam, const RtDevRender &rc, int x0, int y0, int w, int h,
                                  float *rays_out, hipStream_t stream);
 hipError_t rt_launch_resolve(const float *accum, float inv_samples, int width, int height, uint8_t *rgbx, hipStream_t stream);
+hipError_t rt_launch_scatter(const RtDevScene &s, const RtScatterQuery *queries, int n, uint64_t seed, RtScatterResult *out,
+                             hipStream_t stream);
 hipError_t rt_launch_rng_words(const uint32_t *streams, int n, int words_per_stream, uint32_t *out, uint32_t *wyrand_out,
                                hipStream_t stream);
 

@@ -66,9 +66,10 @@ def all_gather_bands(accum, height, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return assemble_bands(accum.unsqueeze(0), height)
-    gathered = torch.empty((world,) + tuple(accum.shape), dtype=accum.dtype, device=accum.device)
+    # the shards concatenated along the rows (the layout every backend accepts), then seen per shard
+    gathered = torch.empty((world * accum.shape[0],) + tuple(accum.shape[1:]), dtype=accum.dtype, device=accum.device)
     dist.all_gather_into_tensor(gathered, accum.contiguous(), group=group)
-    return assemble_bands(gathered, height)
+    return assemble_bands(gathered.reshape((world,) + tuple(accum.shape)), height)
 
 
 # ---------------------------------------------------------------- launching the ranks

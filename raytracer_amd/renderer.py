@@ -16,6 +16,11 @@ from .scene import RenderConfig
 
 HIT_DTYPE = np.dtype([("t", "f4"), ("point", "f4", 3), ("normal", "f4", 3), ("uv", "f4", 2),
                       ("object", "i4"), ("material_offset", "u4"), ("front_face", "i4")])
+SCATTER_QUERY_DTYPE = np.dtype([("direction", "f4", 3), ("normal", "f4", 3), ("point", "f4", 3), ("uv", "f4", 2),
+                                ("front_face", "i4"), ("material_offset", "u4"), ("rng_sample", "u4"), ("rng_x", "u4"), ("rng_y", "u4")])
+SCATTER_RESULT_DTYPE = np.dtype([("scattered", "i4"), ("direction", "f4", 3), ("attenuation", "f4", 3), ("emitted", "f4", 3),
+                                 ("pad", "u4", 2)])
+assert SCATTER_QUERY_DTYPE.itemsize == 64 and SCATTER_RESULT_DTYPE.itemsize == 48
 EVENT_DTYPE = np.dtype([("t", "f4"), ("point", "f4", 3), ("normal", "f4", 3), ("uv", "f4", 2),
                         ("material_offset", "u4"), ("is_exit", "i4"), ("pad", "i4")])
 assert HIT_DTYPE.itemsize == 48 and EVENT_DTYPE.itemsize == 48
@@ -140,6 +145,16 @@ class NativeScene:
         check(lib.rt_first_hit(self.h, r.data_ptr(), n, tmin, tmax, volume_key, out.data_ptr(), _stream()))
         torch.cuda.synchronize(self.ctx.device)
         return out.cpu().numpy()[: n * 48].view(HIT_DTYPE)
+
+    def scatter(self, queries, rng_seed):
+        """One scattering event per query (SCATTER_QUERY_DTYPE array) -> SCATTER_RESULT_DTYPE array."""
+        q = np.ascontiguousarray(queries, dtype=SCATTER_QUERY_DTYPE)
+        n = len(q)
+        dev = torch.from_numpy(q.view(np.uint8).reshape(-1)).to(self.ctx.device)
+        out = torch.zeros(max(n, 1) * 48, dtype=torch.uint8, device=self.ctx.device)
+        check(lib.rt_scatter(self.h, dev.data_ptr(), n, rng_seed, out.data_ptr(), _stream()))
+        torch.cuda.synchronize(self.ctx.device)
+        return out.cpu().numpy()[: n * 48].view(SCATTER_RESULT_DTYPE)
 
     def intervals(self, shape, rays, scripted=None, volume_key=0):
         """Ordered boundary crossings of `shape` along each ray: list of event arrays."""

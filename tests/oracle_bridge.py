@@ -109,6 +109,10 @@ HIT_DTYPE = np.dtype([("t", "f8"), ("point", "f8", 3), ("normal", "f8", 3), ("uv
                       ("material_offset", "u8"), ("object", "i4"), ("front_face", "i4")])
 assert HIT_DTYPE.itemsize == C.sizeof(OrcHit)
 
+SCATTER_QUERY = np.dtype([("direction", "f8", 3), ("normal", "f8", 3), ("point", "f8", 3), ("uv", "f8", 2), ("front_face", "i4"),
+                          ("material_offset", "u4"), ("sample", "u4"), ("x", "u4"), ("y", "u4"), ("pad", "u4")])
+SCATTER_RESULT = np.dtype([("scattered", "i4"), ("pad", "i4"), ("direction", "f8", 3), ("attenuation", "f8", 3), ("emitted", "f8", 3)])
+
 _lib = None
 
 
@@ -279,6 +283,18 @@ class OracleScene:
         _check(self.L.orc_first_hit(self.h, C.c_int(precision), C.c_int(len(rays)), rays.ctypes.data_as(C.c_void_p),
                                     C.c_double(tmin), C.c_double(tmax), C.c_uint64(volume_key),
                                     out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def scatter(self, queries, rng_seed, precision=ORC_F64):
+        """queries: array with the fields of raytracer_amd.renderer.SCATTER_QUERY_DTYPE."""
+        n = len(queries)
+        q = np.zeros(n, dtype=SCATTER_QUERY)
+        for name in ("direction", "normal", "point", "uv", "front_face", "material_offset"):
+            q[name] = queries[name]
+        q["sample"], q["x"], q["y"] = queries["rng_sample"], queries["rng_x"], queries["rng_y"]
+        out = np.zeros(n, dtype=SCATTER_RESULT)
+        _check(self.L.orc_scatter(self.h, C.c_int(precision), C.c_int(n), q.ctypes.data_as(C.c_void_p), C.c_uint64(rng_seed),
+                                  out.ctypes.data_as(C.c_void_p)))
         return out
 
     def render(self, camera, config, width, height, window=None, precision=ORC_F64, threads=0, counters=False):

@@ -58,3 +58,44 @@ def test_two_ranks_equal_one(tmp_path):
     orc = ob.oracle_scene_from(scene)
     ref, _, _ = orc.render(scene.camera, RenderConfig(6, 8, 1, 77, 0), 24, 16, threads=1)
     assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_band_rows_and_assembly():
+    from raytracer_amd.dist import assemble_bands, band_rows
+    for height in (1, 8, 9, 21, 135 * 8, 1080, 2160):
+        for count in (1, 2, 3, 8):
+            rows = [band_rows(height, i, count) for i in range(count)]
+            assert sum(rows) == 8 * ((height + 7) // 8) and rows[0] == max(rows)
+            # every image row lands where assemble_bands looks for it
+            image = torch.arange(height, dtype=torch.float32).reshape(height, 1, 1).expand(height, 2, 3)
+            shards = torch.full((count, rows[0], 2, 3), -1.0)
+            for band in range((height + 7) // 8):
+                n = min(8, height - 8 * band)
+                shards[band % count, 8 * (band // count):8 * (band // count) + n] = image[8 * band:8 * band + n]
+            assert torch.equal(assemble_bands(shards, height), image)
+
+
+def test_launcher_runs_both_exchanges_with_two_ranks(tmp_path):
+    """bench.py --gpus N starts its ranks with raytracer_amd.dist.launch_ranks; here the same launcher
+    starts two CPU ranks (gloo) for each sharding mode, and the exchanged image must be the one a
+    single rank renders: sample-sharded sums added by all-reduce, band shards put together by
+    all-gather."""
+    import oracle_bridge as ob
+    from raytracer_amd import scenes
+    from raytracer_amd.dist import launch_ranks
+    from raytracer_amd.scene import RenderConfig
+    scene = scenes.simple_balls()
+    orc = ob.oracle_scene_from(scene)
+    ref, _, _ = orc.render(scene.camera, RenderConfig(6, 8, 1, 77, 0), 24, 21, threads=1)
+    for mode in ("spp", "bands"):
+        out = str(tmp_path / ("%s.npy" % mode))
+        code, text = launch_ranks([sys.executable, os.path.join(HERE, "dist_worker.py"), mode, out], 2, timeout=300)
+        assert code == 0, text
+        assert "world 2" in text
+        got = np.load(out)
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), mode
+    # a failing rank ends the job with its code instead of leaving the others waiting
+    code, _ = launch_ranks([sys.executable, "-c", "import os, sys, time; sys.exit(7) if os.environ['RANK'] == '1' else time.sleep(60)"],
+                           2, timeout=30)
+    assert code == 7
