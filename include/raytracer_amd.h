@@ -292,6 +292,8 @@ int rt_scene_stats(const RtScene *, RtSceneStats *out);
  * RT_NODES_F16 stores the child boxes as halves rounded outward (32-byte nodes, half the
  * fetch work; boxes only cull, so hits are the same), RT_NODES_F32 keeps the 64-byte nodes,
  * RT_NODES_AUTO (default) takes halves unless a box plane lies beyond +-60000.
+ * RT_OPTION_HEAVY_MIN: how many lanes of a wave must wait at a CSG shape, volume or moving object
+ * before the fused kernel runs those tests (they wait unless nothing else in the wave can move).
  * RT_OPTION_KERNEL_TIMING: 1 records HIP events around every launch of the render loop's
  * dominant kernel for rt_kernel_time (off by default: a viewer that never asks pays nothing).
  * RT_OPTION_PROFILE_PHASES: 1 runs the diagnostic build of the fused kernel that counts
@@ -303,7 +305,7 @@ int rt_scene_stats(const RtScene *, RtSceneStats *out);
  * :245-248,281-282, metal scatter of Material.swift:53-57: absorb on <= 0). */
 enum RtOption {
     RT_OPTION_BVH_BUILDER = 1, RT_OPTION_REFILL_THRESHOLD = 2, RT_OPTION_NODE_MIN = 3, RT_OPTION_NODE_FORMAT = 4,
-    RT_OPTION_KERNEL_TIMING = 5, RT_OPTION_PROFILE_PHASES = 6, RT_OPTION_CONVENTION = 7
+    RT_OPTION_KERNEL_TIMING = 5, RT_OPTION_PROFILE_PHASES = 6, RT_OPTION_CONVENTION = 7, RT_OPTION_HEAVY_MIN = 8
 };
 enum RtBvhBuilder { RT_BVH_MEDIAN_SPLIT = 0, RT_BVH_SAH = 1 };
 enum RtNodeFormat { RT_NODES_AUTO = 0, RT_NODES_F32 = 1, RT_NODES_F16 = 2 };

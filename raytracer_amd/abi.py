@@ -29,7 +29,7 @@ material_kind_isotropic_colored = 9
 background_lighting_none = 0
 background_lighting_sky = 1
 
-RT_OPTION_KERNEL_TIMING, RT_OPTION_PROFILE_PHASES, RT_OPTION_CONVENTION = 5, 6, 7
+RT_OPTION_KERNEL_TIMING, RT_OPTION_PROFILE_PHASES, RT_OPTION_CONVENTION, RT_OPTION_HEAVY_MIN = 5, 6, 7, 8
 RT_CONVENTION_METAL, RT_CONVENTION_KIT = 0, 1
 
 

@@ -389,8 +389,13 @@ RT_DEV Surface prim_surface(const RtDevScene &s, uint32_t ref, uint32_t tag, f3 
 struct CsgIter {
     float tin[RT_CSG_LEAVES], tout[RT_CSG_LEAVES];
     uint64_t tags;            // 3 bits entry tag + 3 bits exit tag per leaf
-    uint32_t n, entered, exited, flip;
-    uint32_t truth[8];
+    uint32_t entered, exited;
+    // The truth table of a shape with at most 5 leaves is one word and stays in a register; a
+    // larger one (6-8 leaves: up to 256 bits) is looked up in the shape's record in memory.
+    // (Eight words selected by a compare chain made the compiler keep this whole struct in
+    // scratch memory: it turned the chain into a select of addresses.)
+    uint32_t truth0;
+    uint32_t wide_csg;        // index of the CSG record when the table is wider than one word, else RT_REF_NONE
     bool inside;
     // current event
     float t;
@@ -398,26 +403,28 @@ struct CsgIter {
     bool is_exit, leaf_exit;
 };
 
-RT_DEV bool csg_lookup(const CsgIter &it, uint32_t mask) {
-    // select chain instead of a runtime index: keeps the table in registers
-    uint32_t hi = mask >> 5, w = it.truth[0];
-#pragma unroll
-    for (uint32_t k = 1; k < 8; k++) w = hi == k ? it.truth[k] : w;
+RT_DEV bool csg_lookup(const RtDevScene &s, const CsgIter &it, uint32_t mask) {
+    uint32_t w = it.truth0;
+    if (it.wide_csg != RT_REF_NONE) w = s.csg[it.wide_csg].truth[mask >> 5];
     return (w >> (mask & 31u)) & 1u;
 }
 
-RT_DEV void csg_begin(const RtDevScene &s, uint32_t idx, f3 o, f3 d, CsgIter &it) {
-    const RtDevCsg &c = s.csg[idx];
-    it.n = c.n_leaves;
-    it.flip = c.flip_mask;
+// Starts the walk over `shape`: a CSG shape, or a primitive taken as a shape of one leaf (inside
+// the shape = inside the leaf).  One loop serves both, so the primitive interval code exists once
+// in a kernel however many kinds of object lead here.
+RT_DEV void csg_begin(const RtDevScene &s, uint32_t shape, f3 o, f3 d, CsgIter &it) {
+    const bool is_csg = ((shape >> RT_KIND_SHIFT) & 7u) == RT_KIND_CSG;
+    const uint32_t idx = shape & RT_INDEX_MASK;
+    const RtDevCsg *c = s.csg + (is_csg ? idx : 0u);
+    const uint32_t n = is_csg ? c->n_leaves : 1u;
     it.tags = 0;
     it.entered = it.exited = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) it.truth[i] = c.truth[i];
+    it.truth0 = is_csg ? c->truth[0] : 2u;         // one leaf: inside exactly when mask = 1
+    it.wide_csg = n > 5u ? idx : RT_REF_NONE;
 #pragma unroll
     for (int i = 0; i < RT_CSG_LEAVES; i++) { it.tin[i] = RT_INF; it.tout[i] = RT_INF; }
-    for (uint32_t i = 0; i < it.n; i++) {
-        Span sp = prim_span(s, c.leaf[i], o, d);
+    for (uint32_t i = 0; i < n; i++) {
+        Span sp = prim_span(s, is_csg ? c->leaf[i] : shape, o, d);
         bool ok = span_valid(sp);
         float a = ok ? sp.t0 : RT_INF, b = ok ? sp.t1 : RT_INF;
 #pragma unroll
@@ -427,12 +434,12 @@ RT_DEV void csg_begin(const RtDevScene &s, uint32_t idx, f3 o, f3 d, CsgIter &it
         it.tags |= (uint64_t)(sp.tag0 | (sp.tag1 << 3)) << (6u * i);
         if (!ok) { it.entered |= 1u << i; it.exited |= 1u << i; }     // nothing left to visit
     }
-    it.inside = csg_lookup(it, 0u);
+    it.inside = csg_lookup(s, it, 0u);
 }
 
 // Advances to the next event of the shape; false when none is left.  An end at +inf is
 // never reached (the reference's merge cannot select it either, RenderableImpl.h:538).
-RT_DEV bool csg_next(CsgIter &it) {
+RT_DEV bool csg_next(const RtDevScene &s, CsgIter &it) {
     while (true) {
         float best = RT_INF;
         int who = -1;
@@ -446,7 +453,7 @@ RT_DEV bool csg_next(CsgIter &it) {
         bool leaf_exit = (it.entered >> who) & 1u;
         if (leaf_exit) it.exited |= 1u << who; else it.entered |= 1u << who;
         uint32_t mask = it.entered & ~it.exited;
-        bool now = csg_lookup(it, mask);
+        bool now = csg_lookup(s, it, mask);
         if (now != it.inside) {
             it.inside = now;
             it.t = best;
@@ -497,7 +504,11 @@ RT_DEV bool in_range(float t, float tmin, float tmax_incl, bool found, float bes
     return t >= tmin && (found ? t < best : t <= tmax_incl);
 }
 
-template <bool SIMPLE, bool MOTION = false>
+RT_DEV uint32_t event_code(const CsgIter &it) { return it.tag | (it.leaf << 3) | ((it.leaf_exit ? 1u : 0u) << 6); }
+
+// LEAN: the kernel is short of registers (texture code next to the intersection code), so a volume
+// over a primitive goes through the general event walk instead of its own few lines.
+template <bool SIMPLE, bool MOTION = false, bool LEAN = false>
 RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmin, float tmax, uint64_t volume_key,
                         const float *scripted, uint32_t n_scripted, bool &found, Best &best, float time = 0.0f) {
     uint32_t kind = (ref >> RT_KIND_SHIFT) & 7u, idx = ref & RT_INDEX_MASK;
@@ -510,7 +521,7 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
         kind = (ref >> RT_KIND_SHIFT) & 7u;
         idx = ref & RT_INDEX_MASK;
     }
-    if (SIMPLE || kind == RT_KIND_SPHERE) {
+    if (SIMPLE) {
         Span sp = sphere_span(s, idx, o, d);
         if (span_valid(sp)) {
             if (in_range(sp.t0, tmin, tmax, found, best.t)) { best.t = sp.t0; best.ref = self; best.code = 0; found = true; }
@@ -518,21 +529,32 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
         }
         return;
     }
-    if (kind <= RT_KIND_QUAD) {
-        Span sp = prim_span(s, ref, o, d);
-        if (span_valid(sp)) {
-            if (in_range(sp.t0, tmin, tmax, found, best.t)) { best.t = sp.t0; best.ref = self; best.code = sp.tag0; found = true; }
-            else if (in_range(sp.t1, tmin, tmax, found, best.t)) { best.t = sp.t1; best.ref = self; best.code = sp.tag1; found = true; }
-        }
-        return;
+    // Every kind goes through one walk over the leaf intervals of a shape: a primitive is a shape
+    // of one leaf, a volume walks its base shape.
+    const bool volume = kind == RT_KIND_CDV;
+    uint32_t shape = ref;
+    float neg_inv_density = 0.0f;
+    if (volume) {
+        const RtDevCdv cv = s.cdv[idx];
+        shape = cv.base;
+        neg_inv_density = cv.neg_inv_density;
     }
-    if (kind == RT_KIND_CSG) {
-        CsgIter it;
-        csg_begin(s, idx, o, d, it);
-        while (csg_next(it)) {
+    CsgIter it;
+    csg_begin(s, shape, o, d, it);
+    if (!volume) {
+        if (kind <= RT_KIND_QUAD) {
+            // one interval: entry, else exit (Shaders.metal:182-199 on a two-hit enumerator)
+            const float t0 = it.tin[0], t1 = it.tout[0];
+            if (!(it.entered & 1u)) {
+                if (in_range(t0, tmin, tmax, found, best.t)) { best.t = t0; best.ref = self; best.code = (uint32_t)it.tags & 7u; found = true; }
+                else if (in_range(t1, tmin, tmax, found, best.t)) { best.t = t1; best.ref = self; best.code = ((uint32_t)it.tags >> 3) & 7u; found = true; }
+            }
+            return;
+        }
+        while (csg_next(s, it)) {
             if (in_range(it.t, tmin, tmax, found, best.t)) {
                 best.t = it.t; best.ref = self;
-                best.code = it.tag | (it.leaf << 3) | ((it.leaf_exit ? 1u : 0u) << 6);
+                best.code = event_code(it);
                 found = true;
                 break;
             }
@@ -542,40 +564,38 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
     }
     // Constant-density volume, RenderableImpl.h:737-777: one free-flight draw per interval of
     // the base shape; a scatter inside the interval is followed by the interval's exit.
-    const RtDevCdv cv = s.cdv[idx];
-    uint32_t draw = 0;
-    uint32_t bkind = (cv.base >> RT_KIND_SHIFT) & 7u;
-    if (bkind != RT_KIND_CSG) {
-        Span sp = prim_span(s, cv.base, o, d);
-        if (!span_valid(sp)) return;
-        float t1 = fmaxf(0.0f, sp.t0), t2 = sp.t1;
+    if (!LEAN && ((shape >> RT_KIND_SHIFT) & 7u) != RT_KIND_CSG) {
+        // a primitive base has one interval: no event walk needed
+        if (it.entered & 1u) return;
+        const float t1 = fmaxf(0.0f, it.tin[0]), t2 = it.tout[0];
         if (!(t1 < t2)) return;
         if (found && best.t <= t1) return;      // nothing inside the medium can beat the current hit
         float u;
-        if (scripted) u = scripted[draw % n_scripted];
+        if (scripted) u = scripted[0];
         else { Pcg vr = pcg_seed(volume_key, (uint64_t)(s.cdv_obj[idx] + 1u)); u = rnd(vr); }
-        float t = fmaf(logf(1.0f - u), cv.neg_inv_density, t1);
+        const float t = fmaf(logf(1.0f - u), neg_inv_density, t1);
         if (!(t <= t2)) return;
-        if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = self; best.code = RT_CODE_SCATTER | sp.tag0; found = true; }
-        else if (in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = self; best.code = sp.tag1; found = true; }
+        if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = self; best.code = RT_CODE_SCATTER | ((uint32_t)it.tags & 7u); found = true; }
+        else if (in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = self; best.code = ((uint32_t)it.tags >> 3) & 7u; found = true; }
         return;
     }
-    Pcg vr = pcg_seed(volume_key, (uint64_t)(s.cdv_obj[idx] + 1u));
-    CsgIter it;
-    csg_begin(s, cv.base & RT_INDEX_MASK, o, d, it);
-    uint32_t interval = 0;
-    while (csg_next(it)) {
+    Pcg vr;
+    vr.state = vr.inc = 0;
+    uint32_t draw = 0, interval = 0;
+    while (csg_next(s, it)) {
         float t_entry = it.t;
-        uint32_t entry_code = it.tag | (it.leaf << 3) | ((it.leaf_exit ? 1u : 0u) << 6);
+        uint32_t entry_code = event_code(it);
         float t2 = RT_INF;
         uint32_t exit_code = 0;
-        bool has_exit = csg_next(it);
-        if (has_exit) { t2 = it.t; exit_code = it.tag | (it.leaf << 3) | ((it.leaf_exit ? 1u : 0u) << 6); }
+        bool has_exit = csg_next(s, it);
+        if (has_exit) { t2 = it.t; exit_code = event_code(it); }
         float t1 = fmaxf(0.0f, t_entry);
+        if (found && best.t <= t1) return;      // nothing in this or a later interval can beat the current hit
         if (t1 < t2) {
+            if (!scripted && draw == 0) vr = pcg_seed(volume_key, (uint64_t)(s.cdv_obj[idx] + 1u));
             float u = scripted ? scripted[draw % n_scripted] : rnd(vr);
             draw++;
-            float t = fmaf(logf(1.0f - u), cv.neg_inv_density, t1);
+            float t = fmaf(logf(1.0f - u), neg_inv_density, t1);
             if (t <= t2) {
                 uint32_t iv = interval << RT_CODE_INTERVAL_SHIFT;
                 if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = self; best.code = RT_CODE_SCATTER | iv | entry_code; found = true; return; }
@@ -766,32 +786,19 @@ RT_DEV Surface csg_surface(const RtDevScene &s, uint32_t csg_idx, uint32_t code,
     return sf;
 }
 
-// Re-finds interval number `interval` of a CSG base and returns its entry distance and code.
-RT_DEV void csg_entry_of_interval(const RtDevScene &s, uint32_t csg_idx, f3 o, f3 d, uint32_t interval, float &t, uint32_t &code) {
-    CsgIter it;
-    csg_begin(s, csg_idx, o, d, it);
-    t = 0.0f; code = 0;
-    for (uint32_t k = 0; csg_next(it); k++) {
-        if (k == 2u * interval) {
-            t = it.t;
-            code = it.tag | (it.leaf << 3) | ((it.leaf_exit ? 1u : 0u) << 6);
-            return;
-        }
-    }
-}
-
+// Surface attributes of the closest hit.  Whatever the object's kind, the hit lies on one leaf
+// primitive (named by best.code for CSG shapes), so the attribute code is reached from one place.
 template <bool MOTION = false>
 RT_DEV void complete_hit(const RtDevScene &s, Best best, f3 o, f3 d, bool want_uv, HitRecord &h, float time = 0.0f) {
     uint32_t kind = (best.ref >> RT_KIND_SHIFT) & 7u, idx = best.ref & RT_INDEX_MASK;
-    Surface sf;
     h.point = madd(d, best.t, o);
     const f3 world_d = d;
     MotionFrame frame;
     bool moved = false;
-    uint32_t moving_object = 0;
+    uint32_t object = 0;
     if (MOTION && kind == RT_KIND_MOTION) {
         frame = motion_frame(s, idx, time);
-        moving_object = s.motion_obj[idx];
+        object = s.motion_obj[idx];
         o = frame_in(frame, o - frame.t);
         d = frame_in(frame, d);
         best.ref = frame.base;
@@ -799,42 +806,36 @@ RT_DEV void complete_hit(const RtDevScene &s, Best best, f3 o, f3 d, bool want_u
         idx = best.ref & RT_INDEX_MASK;
         moved = true;
     }
-    if (kind == RT_KIND_SPHERE) {
-        sf = prim_surface(s, best.ref, 0, o, d, best.t, want_uv);
-        h.object = s.sphere_obj[idx];
-    } else if (kind <= RT_KIND_QUAD) {
-        sf = prim_surface(s, best.ref, best.code & 7u, o, d, best.t, want_uv);
-        h.object = s.xprim_obj[idx];
-    } else if (kind == RT_KIND_CSG) {
-        sf = csg_surface(s, idx, best.code, o, d, best.t, want_uv);
-        h.object = s.csg_obj[idx];
-    } else {
-        const RtDevCdv cv = s.cdv[idx];
-        h.object = s.cdv_obj[idx];
-        uint32_t bkind = (cv.base >> RT_KIND_SHIFT) & 7u;
-        bool scatter = best.code & RT_CODE_SCATTER;
-        if (!scatter) {
-            // boundary exit of the base shape
-            if (bkind == RT_KIND_CSG) sf = csg_surface(s, cv.base & RT_INDEX_MASK, best.code, o, d, best.t, want_uv);
-            else sf = prim_surface(s, cv.base, best.code & 7u, o, d, best.t, want_uv);
-        } else {
-            // RenderableImpl.h:760-766: point on the ray, normal against the ray, material and
-            // texture coordinates of the ENTRY hit of the interval
-            if (bkind == RT_KIND_CSG) {
-                float te; uint32_t ce;
-                csg_entry_of_interval(s, cv.base & RT_INDEX_MASK, o, d, (best.code & 0x7FFFFFFFu) >> RT_CODE_INTERVAL_SHIFT, te, ce);
-                sf = csg_surface(s, cv.base & RT_INDEX_MASK, ce, o, d, te, true);
-            } else {
-                Span sp = prim_span(s, cv.base, o, d);
-                sf = prim_surface(s, cv.base, best.code & 7u, o, d, sp.t0, true);
-            }
-            sf.normal = -d;
-        }
+    uint32_t shape = best.ref;
+    const bool scatter = kind == RT_KIND_CDV && (best.code & RT_CODE_SCATTER);
+    if (kind == RT_KIND_CDV) {
+        if (!moved) object = s.cdv_obj[idx];
+        shape = s.cdv[idx].base;
     }
-    if (MOTION && moved) {
-        sf.normal = frame_out(frame, sf.normal);
-        h.object = moving_object;
+    const uint32_t skind = (shape >> RT_KIND_SHIFT) & 7u, sidx = shape & RT_INDEX_MASK;
+    uint32_t leaf_ref = shape;
+    bool flip = false;
+    if (skind == RT_KIND_CSG) {
+        const RtDevCsg &c = s.csg[sidx];
+        const uint32_t leaf = (best.code >> 3) & 7u;
+        leaf_ref = c.leaf[leaf];
+        flip = (c.flip_mask >> leaf) & 1u;                         // RenderableImpl.h:712
+        if (kind == RT_KIND_CSG && !moved) object = s.csg_obj[sidx];
+    } else if (kind != RT_KIND_CDV && !moved) {
+        object = skind == RT_KIND_SPHERE ? s.sphere_obj[sidx] : s.xprim_obj[sidx];
     }
+    float t_surface = best.t;
+    if (scatter) {
+        // RenderableImpl.h:760-766: point on the ray, normal against the ray, material and texture
+        // coordinates of the ENTRY hit of the interval, which lies on leaf_ref at its entry or exit
+        Span sp = prim_span(s, leaf_ref, o, d);
+        t_surface = ((best.code >> 6) & 1u) ? sp.t1 : sp.t0;
+    }
+    Surface sf = prim_surface(s, leaf_ref, best.code & 7u, o, d, t_surface, want_uv || scatter);
+    if (flip) sf.normal = -sf.normal;
+    if (scatter) sf.normal = -d;
+    if (MOTION && moved) sf.normal = frame_out(frame, sf.normal);
+    h.object = object;
     h.u = sf.u; h.v = sf.v;
     h.material = sf.material;
     if (dot(sf.normal, world_d) > 0.0f) { h.normal = -sf.normal; h.front = false; }

@@ -119,8 +119,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intervals(RtDevScene s, uint32_t r
         }
     } else if (kind == RT_KIND_CSG) {
         CsgIter it;
-        csg_begin(s, idx, o, d, it);
-        while (csg_next(it)) {
+        csg_begin(s, ref, o, d, it);
+        while (csg_next(s, it)) {
             uint32_t code = it.tag | (it.leaf << 3);
             Surface sf;
             if (finite(it.t)) sf = csg_surface(s, idx, code, o, d, it.t, true);
@@ -135,16 +135,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intervals(RtDevScene s, uint32_t r
         CsgIter it;
         Span sp = empty_span();
         bool prim_pending = false;
-        if (bkind == RT_KIND_CSG) csg_begin(s, bidx, o, d, it);
+        if (bkind == RT_KIND_CSG) csg_begin(s, cv.base, o, d, it);
         else { sp = prim_span(s, cv.base, o, d); prim_pending = span_valid(sp); }
         while (true) {
             float t_entry, t_exit = RT_INF;
             uint32_t entry_code, exit_code = 0;
             bool has_exit;
             if (bkind == RT_KIND_CSG) {
-                if (!csg_next(it)) break;
+                if (!csg_next(s, it)) break;
                 t_entry = it.t; entry_code = it.tag | (it.leaf << 3);
-                has_exit = csg_next(it);
+                has_exit = csg_next(s, it);
                 if (has_exit) { t_exit = it.t; exit_code = it.tag | (it.leaf << 3); }
             } else {
                 if (!prim_pending) break;
@@ -502,7 +502,7 @@ __global__ void k_fused_setup(uint32_t *workspace, RtDevCamera cam) {
 template <int FEAT, bool PROF, int STACK, int WPS, bool NODE16, bool DEEP = false>
 __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtDevCamera *camp, uint32_t background, RtDevRender rc, float *accum,
                                                      uint32_t *counter, uint32_t n_items, uint32_t tiles_x,
-                                                     uint32_t n_tiles, uint32_t chunk_spp, uint32_t knobs) {
+                                                     uint32_t n_tiles, uint32_t chunk_spp, uint32_t knobs, uint32_t heavy_min) {
     __shared__ uint32_t stack_mem[STACK * RT_BLOCK];
     constexpr int LDS_ENTRIES = DEEP ? STACK : 0;
     DeepStack deep_cols;
@@ -653,13 +653,21 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
         while (true) {
             // node steps go on while enough lanes sit on inner nodes; once fewer than
             // node_min do and some lane waits at a leaf, or leaf_max lanes wait there, the
-            // leaf tests get their turn
+            // leaf tests get their turn.  Heavy leaves (CSG shapes, volumes, moving objects: an
+            // order of magnitude more instructions than a primitive, and rare) are held back
+            // until heavy_min lanes wait at one or nothing else can move: the wave then runs
+            // that code once for many lanes instead of once per lane.
             while (true) {
-                bool inner = !(t.cur & RT_REF_LEAF);
-                uint32_t n_inner = (uint32_t)__popcll(__ballot(inner));
+                const bool inner = !(t.cur & RT_REF_LEAF);
+                const uint32_t n_inner = (uint32_t)__popcll(__ballot(inner));
                 if (n_inner == 0) break;
-                const uint32_t n_leaf = (uint32_t)__popcll(__ballot(!inner && t.cur != RT_REF_NONE));
-                if ((n_inner < node_min && n_leaf) || n_leaf >= leaf_max) break;
+                const bool waits = !inner && t.cur != RT_REF_NONE;
+                uint32_t n_ready = (uint32_t)__popcll(__ballot(waits));
+                if (!SIMPLE) {
+                    const uint32_t n_heavy = (uint32_t)__popcll(__ballot(waits && ((t.cur >> RT_KIND_SHIFT) & 7u) >= RT_KIND_CSG));
+                    if (n_heavy < heavy_min) n_ready -= n_heavy;
+                }
+                if ((n_inner < node_min && n_ready) || n_ready >= leaf_max) break;
                 RT_PROF_BEGIN();
                 if (inner) {
                     if (NODE16) trav_node16<LDS_ENTRIES>(nodes16, t, RT_T_MIN, stack, deep);
@@ -668,9 +676,18 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
                 RT_PROF_END(2, inner);
             }
             RT_PROF_BEGIN();
-            const bool at_leaf = (t.cur & RT_REF_LEAF) && t.cur != RT_REF_NONE;
+            bool at_leaf = (t.cur & RT_REF_LEAF) && t.cur != RT_REF_NONE;
+            if (!SIMPLE) {
+                const bool heavy = at_leaf && ((t.cur >> RT_KIND_SHIFT) & 7u) >= RT_KIND_CSG;
+                const uint32_t n_heavy = (uint32_t)__popcll(__ballot(heavy));
+                if (n_heavy && n_heavy < heavy_min) {
+                    // held back unless nothing else can move: no lane on an inner node, none at a light leaf
+                    const bool others = __ballot(!(t.cur & RT_REF_LEAF) || (at_leaf && !heavy)) != 0;
+                    if (others) at_leaf = at_leaf && !heavy;
+                }
+            }
             if (at_leaf) {
-                test_object<SIMPLE, (FEAT & RT_FEAT_MOTION) != 0>(s, t.cur & ~RT_REF_LEAF, t.o, t.d, RT_T_MIN, RT_INF, key, nullptr, 0, t.found, t.best, time);
+                test_object<SIMPLE, (FEAT & RT_FEAT_MOTION) != 0, (FEAT & RT_FEAT_TEXTURE) != 0>(s, t.cur & ~RT_REF_LEAF, t.o, t.d, RT_T_MIN, RT_INF, key, nullptr, 0, t.found, t.best, time);
                 trav_pop<LDS_ENTRIES>(t, stack, deep);
             }
             RT_PROF_END(3, at_leaf);
@@ -850,7 +867,7 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
 
 template <int FEAT, int STACK, int WPS, bool NODE16, bool DEEP = false>
 static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, const RtDevRender &rc, float *accum,
-                               uint32_t *counter, uint32_t knobs, hipStream_t stream, RtKernelTimer *timer, int cus,
+                               uint32_t *counter, uint32_t knobs, uint32_t knobs2, hipStream_t stream, RtKernelTimer *timer, int cus,
                                bool prepare_only) {
     // tile rows of this shard (all of them when band_count is 1)
     const uint32_t all_rows = (rc.height + 7u) / 8u;
@@ -890,16 +907,16 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     const RtDevCamera *camp = (const RtDevCamera *)((const char *)counter + RT_FUSED_CAMERA_OFFSET);
     if (timer) timer->begin(stream);
     if (prof)
-        k_fused<FEAT, true, STACK, WPS, NODE16, DEEP><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
+        k_fused<FEAT, true, STACK, WPS, NODE16, DEEP><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u));
     else
-        k_fused<FEAT, false, STACK, WPS, NODE16, DEEP><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs);
+        k_fused<FEAT, false, STACK, WPS, NODE16, DEEP><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u));
     if (timer) timer->end(stream);
     return hipGetLastError();
 }
 
 hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_depth, const RtDevCamera &cam, RtDevRender rc,
                            uint32_t knobs, float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
-                           RtKernelTimer *timer, int cus, bool prepare_only) {
+                           RtKernelTimer *timer, int cus, bool prepare_only, uint32_t knobs2) {
     if (!prepare_only) {
         if (rc.width == 0 || rc.height == 0 || rc.spp == 0) return hipSuccess;
         if (workspace_bytes < RT_FUSED_HEADER || rc.band_count == 0 || rc.band_index >= rc.band_count) return hipErrorInvalidValue;
@@ -907,16 +924,16 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
     if (timer) timer->name = "k_fused";
     uint32_t *counter = (uint32_t *)workspace;
     const bool n16 = (knobs & 0x20000u) != 0 && s.nodes16 != nullptr;
-#define RT_FUSED(F, ST, W) (n16 ? fused_launch<F, ST, W, true>(s, cam, rc, accum, counter, knobs, stream, timer, cus, prepare_only) \
-                                : fused_launch<F, ST, W, false>(s, cam, rc, accum, counter, knobs, stream, timer, cus, prepare_only))
+#define RT_FUSED(F, ST, W) (n16 ? fused_launch<F, ST, W, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only) \
+                                : fused_launch<F, ST, W, false>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only))
     switch (feat & 7u) {
     case 0:
         if (bvh_depth <= 16) return RT_FUSED(0, 16, 8);
         // a deep tree (a million spheres) waits on memory, not on the ALUs: 8 waves per SIMD with
         // the rare deep stack entries in global memory beat 5 waves with the whole stack in LDS
         if (workspace_bytes >= rt_fused_workspace_bytes(cus) || prepare_only) {
-            hipError_t e = n16 ? fused_launch<0, 16, 8, true, true>(s, cam, rc, accum, counter, knobs, stream, timer, cus, prepare_only)
-                               : fused_launch<0, 16, 8, false, true>(s, cam, rc, accum, counter, knobs, stream, timer, cus, prepare_only);
+            hipError_t e = n16 ? fused_launch<0, 16, 8, true, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only)
+                               : fused_launch<0, 16, 8, false, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
             if (!prepare_only) return e;
         }
         return RT_FUSED(0, RT_STACK_DEPTH, 5);
@@ -951,9 +968,9 @@ hipError_t rt_static_scratch_init(int device) {
 }
 
 hipError_t rt_render_fused_static(const RtDevScene &s, uint32_t feat, uint32_t bvh_depth, const RtDevCamera &cam, RtDevRender rc,
-                                  uint32_t knobs, float *accum, hipStream_t stream, int cus, int device) {
+                                  uint32_t knobs, float *accum, hipStream_t stream, int cus, int device, uint32_t knobs2) {
     if (device < 0 || device >= RT_STATIC_MAX_DEVICES || !scratch_of_device[device]) return hipErrorNotInitialized;
     // a device with more compute units than the columns were sized for runs the grid of RT_STATIC_MAX_CUS units
     return rt_render_fused(s, feat, bvh_depth, cam, rc, knobs, accum, scratch_of_device[device], RT_STATIC_SCRATCH_BYTES, stream,
-                           nullptr, std::min(cus, RT_STATIC_MAX_CUS), false);
+                           nullptr, std::min(cus, RT_STATIC_MAX_CUS), false, knobs2);
 }

@@ -98,12 +98,14 @@ hipError_t rt_launch_progressive_present(const float *pass_sum, uint32_t spp, ui
 hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc,
                                float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
                                RtKernelTimer *timer, int cus);
+// knobs2: bits 0-6 = heavy_min (lanes that must wait at a CSG shape / volume / moving object before
+// the wave runs that code; 0 or 1 = never held back).
 // prepare_only: no launch; makes the runtime queries a later call of the same scene would make
 // (workgroups per compute unit of the kernel variants the scene selects), so that render calls
 // themselves query nothing.
 hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_depth, const RtDevCamera &cam, RtDevRender rc,
                            uint32_t knobs, float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
-                           RtKernelTimer *timer, int cus, bool prepare_only = false);
+                           RtKernelTimer *timer, int cus, bool prepare_only = false, uint32_t knobs2 = 0);
 
 // The fused kernel on the library's own per-device scratch array (no workspace argument, no
 // allocation, no timing events).  rt_static_scratch_init(device) resolves the array's address on
@@ -112,7 +114,7 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
 #define RT_STATIC_MAX_DEVICES 64
 hipError_t rt_static_scratch_init(int device);
 hipError_t rt_render_fused_static(const RtDevScene &s, uint32_t feat, uint32_t bvh_depth, const RtDevCamera &cam, RtDevRender rc,
-                                  uint32_t knobs, float *accum, hipStream_t stream, int cus, int device);
+                                  uint32_t knobs, float *accum, hipStream_t stream, int cus, int device, uint32_t knobs2);
 
 #define RT_WAVEFRONT_BATCH_SPP 8u      // samples per pixel resident in the path queues at once
 #define RT_FUSED_HEADER 4096u          // the least workspace the fused kernel runs with
