@@ -20,6 +20,8 @@
 #include "rt_device.h"
 #include "rt_launch.h"
 
+#define RT_WPS0 8              // waves per SIMD of the spheres-only kernel (64 VGPRs)
+#define RT_WPS_DEEP 7          // ... of its deep-tree form: 72 VGPRs, measured +5 % on the million-sphere workload over 8 (6: +-0)
 #define RT_T_MIN 1e-3f          // Camera.swift:117
 #define RT_WAVES (RT_BLOCK / 64)
 
@@ -928,12 +930,12 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
                                 : fused_launch<F, ST, W, false>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only))
     switch (feat & 7u) {
     case 0:
-        if (bvh_depth <= 16) return RT_FUSED(0, 16, 8);
+        if (bvh_depth <= 16) return RT_FUSED(0, 16, RT_WPS0);
         // a deep tree (a million spheres) waits on memory, not on the ALUs: 8 waves per SIMD with
         // the rare deep stack entries in global memory beat 5 waves with the whole stack in LDS
         if (workspace_bytes >= rt_fused_workspace_bytes(cus) || prepare_only) {
-            hipError_t e = n16 ? fused_launch<0, 16, 8, true, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only)
-                               : fused_launch<0, 16, 8, false, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
+            hipError_t e = n16 ? fused_launch<0, 16, RT_WPS_DEEP, true, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only)
+                               : fused_launch<0, 16, RT_WPS_DEEP, false, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
             if (!prepare_only) return e;
         }
         return RT_FUSED(0, RT_STACK_DEPTH, 5);

@@ -22,7 +22,10 @@ from raytracer_amd.renderer import Renderer  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg2_random_spheres_1080p"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 scene, w, h, _, depth, seed = scenes.make_workload(name)
-r = Renderer(scene, w, h, profile_phases=True)
+import os as _os
+from raytracer_amd import abi  # noqa: E402
+_nodes = {"auto": abi.RT_NODES_AUTO, "f32": abi.RT_NODES_F32, "f16": abi.RT_NODES_F16}[_os.environ.get("RT_NODES", "auto")]
+r = Renderer(scene, w, h, profile_phases=True, nodes=_nodes)
 r.draw(spp, depth, seed)
 torch.cuda.synchronize()
 pc = r.workspace[256:256 + 96].cpu().numpy().view(np.uint64).reshape(4, 3)
