@@ -85,6 +85,7 @@ def parse_args():
     ap.add_argument("--node-min", type=int, default=-1)
     ap.add_argument("--nodes", default="auto", choices=["auto", "f32", "f16"])
     ap.add_argument("--heavy-min", type=int, default=-1)
+    ap.add_argument("--traversal", default="auto", choices=["auto", "tree", "list"])
     return ap.parse_args()
 
 
@@ -153,7 +154,8 @@ def main():
                  bvh=abi.RT_BVH_SAH if args.bvh == "sah" else abi.RT_BVH_MEDIAN_SPLIT, refill=args.refill or None,
                  node_min=None if args.node_min < 0 else args.node_min,
                  nodes={"auto": abi.RT_NODES_AUTO, "f32": abi.RT_NODES_F32, "f16": abi.RT_NODES_F16}[args.nodes],
-                 timing=True, bands=(rank, world) if bands else None, heavy_min=None if args.heavy_min < 0 else args.heavy_min)
+                 timing=True, bands=(rank, world) if bands else None, heavy_min=None if args.heavy_min < 0 else args.heavy_min,
+                 traversal={"auto": abi.RT_TRAVERSAL_AUTO, "tree": abi.RT_TRAVERSAL_TREE, "list": abi.RT_TRAVERSAL_LIST}[args.traversal])
 
     trace = bool(os.environ.get("RT_BENCH_TRACE"))
     image = [None]

@@ -294,6 +294,11 @@ int rt_scene_stats(const RtScene *, RtSceneStats *out);
  * RT_NODES_AUTO (default) takes halves unless a box plane lies beyond +-60000.
  * RT_OPTION_HEAVY_MIN: how many lanes of a wave must wait at a CSG shape, volume or moving object
  * before the fused kernel runs those tests (they wait unless nothing else in the wave can move).
+ * RT_OPTION_TRAVERSAL: how rt_render's fused kernel finds the closest hit.  RT_TRAVERSAL_LIST tests every
+ * object in turn (Array<any Hittable>.hit, RayTracingKit/Hittable.swift:662-671), all lanes of a wave
+ * the same object at once: for scenes of at most 16 objects, where a tree only adds divergence;
+ * RT_TRAVERSAL_TREE walks the BVH; RT_TRAVERSAL_AUTO (default) takes the list when the scene has one.
+ * Hits are the same (ties between two objects at exactly the same distance may resolve differently).
  * RT_OPTION_KERNEL_TIMING: 1 records HIP events around every launch of the render loop's
  * dominant kernel for rt_kernel_time (off by default: a viewer that never asks pays nothing).
  * RT_OPTION_PROFILE_PHASES: 1 runs the diagnostic build of the fused kernel that counts
@@ -305,8 +310,10 @@ int rt_scene_stats(const RtScene *, RtSceneStats *out);
  * :245-248,281-282, metal scatter of Material.swift:53-57: absorb on <= 0). */
 enum RtOption {
     RT_OPTION_BVH_BUILDER = 1, RT_OPTION_REFILL_THRESHOLD = 2, RT_OPTION_NODE_MIN = 3, RT_OPTION_NODE_FORMAT = 4,
-    RT_OPTION_KERNEL_TIMING = 5, RT_OPTION_PROFILE_PHASES = 6, RT_OPTION_CONVENTION = 7, RT_OPTION_HEAVY_MIN = 8
+    RT_OPTION_KERNEL_TIMING = 5, RT_OPTION_PROFILE_PHASES = 6, RT_OPTION_CONVENTION = 7, RT_OPTION_HEAVY_MIN = 8,
+    RT_OPTION_TRAVERSAL = 9
 };
+enum RtTraversal { RT_TRAVERSAL_AUTO = 0, RT_TRAVERSAL_TREE = 1, RT_TRAVERSAL_LIST = 2 };
 enum RtBvhBuilder { RT_BVH_MEDIAN_SPLIT = 0, RT_BVH_SAH = 1 };
 enum RtNodeFormat { RT_NODES_AUTO = 0, RT_NODES_F32 = 1, RT_NODES_F16 = 2 };
 enum RtConvention { RT_CONVENTION_METAL = 0, RT_CONVENTION_KIT = 1 };

@@ -30,6 +30,8 @@ background_lighting_none = 0
 background_lighting_sky = 1
 
 RT_OPTION_KERNEL_TIMING, RT_OPTION_PROFILE_PHASES, RT_OPTION_CONVENTION, RT_OPTION_HEAVY_MIN = 5, 6, 7, 8
+RT_OPTION_TRAVERSAL = 9
+RT_TRAVERSAL_AUTO, RT_TRAVERSAL_TREE, RT_TRAVERSAL_LIST = 0, 1, 2
 RT_CONVENTION_METAL, RT_CONVENTION_KIT = 0, 1
 
 

@@ -150,10 +150,21 @@ struct Span { float t0, t1; uint32_t tag0, tag1; };
 RT_DEV Span empty_span() { Span s; s.t0 = RT_INF; s.t1 = -RT_INF; s.tag0 = s.tag1 = 0; return s; }
 RT_DEV bool span_valid(const Span &s) { return s.t0 <= s.t1; }
 
+// UNI = the address is the same in every lane of the wave and the scene data is never written while
+// a kernel runs: the load is typed as one from constant memory, which lets it go through the scalar
+// cache into scalar registers (one request per wave instead of one per lane).
+template <bool UNI, class T> RT_DEV T ld(const T *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (UNI) return *(const __attribute__((address_space(4))) T *)(uintptr_t)p;
+#endif
+    return *p;
+}
+
 struct XPrim { f3 c0, c1, c2, t; float p0, p1, p2, p3; };
+template <bool UNI = false>
 RT_DEV XPrim load_xprim(const RtDevScene &s, uint32_t idx) {
     const float4 *q = (const float4 *)s.xprims + 4u * idx;
-    float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    float4 a = ld<UNI>(q), b = ld<UNI>(q + 1), c = ld<UNI>(q + 2), d = ld<UNI>(q + 3);
     XPrim x;
     x.c0 = mk3(a.x, a.y, a.z);
     x.c1 = mk3(a.w, b.x, b.y);
@@ -167,8 +178,9 @@ RT_DEV f3 rot(const XPrim &x, f3 v) { return madd(x.c0, v.x, madd(x.c1, v.y, x.c
 
 // Impl/RenderableImpl.h:30-56.  The discriminant is taken as a*(r^2 - |oc - (b/a) d|^2):
 // the same number as b^2 - a*c without subtracting two large squares.
+template <bool UNI = false>
 RT_DEV Span sphere_span(const RtDevScene &s, uint32_t idx, f3 o, f3 d) {
-    float4 g = ((const float4 *)s.spheres)[idx];
+    float4 g = ld<UNI>((const float4 *)s.spheres + idx);
     f3 oc = o - mk3(g.x, g.y, g.z);
     float a = dot(d, d);
     float b = dot(d, oc);
@@ -281,10 +293,11 @@ RT_DEV Span quad_span(const XPrim &x, f3 o, f3 d, float &alpha, float &beta) {
     return sp;
 }
 
+template <bool UNI = false>
 RT_DEV Span prim_span(const RtDevScene &s, uint32_t ref, f3 o, f3 d) {
     uint32_t kind = (ref >> RT_KIND_SHIFT) & 7u, idx = ref & RT_INDEX_MASK;
-    if (kind == RT_KIND_SPHERE) return sphere_span(s, idx, o, d);
-    XPrim x = load_xprim(s, idx);
+    if (kind == RT_KIND_SPHERE) return sphere_span<UNI>(s, idx, o, d);
+    XPrim x = load_xprim<UNI>(s, idx);
     if (kind == RT_KIND_CYLINDER) return cylinder_span(x, o, d);
     if (kind == RT_KIND_CUBOID) return cuboid_span(x, o, d);
     float al, be;
@@ -405,26 +418,27 @@ struct CsgIter {
 
 RT_DEV bool csg_lookup(const RtDevScene &s, const CsgIter &it, uint32_t mask) {
     uint32_t w = it.truth0;
-    if (it.wide_csg != RT_REF_NONE) w = s.csg[it.wide_csg].truth[mask >> 5];
+    if (it.wide_csg != RT_REF_NONE) w = s.csg[it.wide_csg].truth[mask >> 5];       // the mask differs from lane to lane
     return (w >> (mask & 31u)) & 1u;
 }
 
 // Starts the walk over `shape`: a CSG shape, or a primitive taken as a shape of one leaf (inside
 // the shape = inside the leaf).  One loop serves both, so the primitive interval code exists once
 // in a kernel however many kinds of object lead here.
+template <bool UNI = false>
 RT_DEV void csg_begin(const RtDevScene &s, uint32_t shape, f3 o, f3 d, CsgIter &it) {
     const bool is_csg = ((shape >> RT_KIND_SHIFT) & 7u) == RT_KIND_CSG;
     const uint32_t idx = shape & RT_INDEX_MASK;
     const RtDevCsg *c = s.csg + (is_csg ? idx : 0u);
-    const uint32_t n = is_csg ? c->n_leaves : 1u;
+    const uint32_t n = is_csg ? ld<UNI>(&c->n_leaves) : 1u;
     it.tags = 0;
     it.entered = it.exited = 0;
-    it.truth0 = is_csg ? c->truth[0] : 2u;         // one leaf: inside exactly when mask = 1
+    it.truth0 = is_csg ? ld<UNI>(&c->truth[0]) : 2u;         // one leaf: inside exactly when mask = 1
     it.wide_csg = n > 5u ? idx : RT_REF_NONE;
 #pragma unroll
     for (int i = 0; i < RT_CSG_LEAVES; i++) { it.tin[i] = RT_INF; it.tout[i] = RT_INF; }
     for (uint32_t i = 0; i < n; i++) {
-        Span sp = prim_span(s, is_csg ? c->leaf[i] : shape, o, d);
+        Span sp = prim_span<UNI>(s, is_csg ? ld<UNI>(&c->leaf[i]) : shape, o, d);
         bool ok = span_valid(sp);
         float a = ok ? sp.t0 : RT_INF, b = ok ? sp.t1 : RT_INF;
 #pragma unroll
@@ -504,11 +518,30 @@ RT_DEV bool in_range(float t, float tmin, float tmax_incl, bool found, float bes
     return t >= tmin && (found ? t < best : t <= tmax_incl);
 }
 
+// Constant-density volume over a primitive (one interval [t_in, t_out]), RenderableImpl.h:737-777:
+// one free-flight draw; a scatter inside the interval, else the interval's exit.
+template <bool UNI>
+RT_DEV void volume_over_primitive(const RtDevScene &s, uint32_t cdv_idx, uint32_t self, float t_in, float t_out, uint32_t tag_in,
+                                  uint32_t tag_out, float neg_inv_density, float tmin, float tmax, uint64_t volume_key,
+                                  const float *scripted, bool &found, Best &best) {
+    const float t1 = fmaxf(0.0f, t_in), t2 = t_out;
+    if (!(t1 < t2)) return;
+    if (found && best.t <= t1) return;      // nothing inside the medium can beat the current hit
+    float u;
+    if (scripted) u = scripted[0];
+    else { Pcg vr = pcg_seed(volume_key, (uint64_t)(ld<UNI>(s.cdv_obj + cdv_idx) + 1u)); u = rnd(vr); }
+    const float t = fmaf(logf(1.0f - u), neg_inv_density, t1);
+    if (!(t <= t2)) return;
+    if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = self; best.code = RT_CODE_SCATTER | tag_in; found = true; }
+    else if (in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = self; best.code = tag_out; found = true; }
+}
+
 RT_DEV uint32_t event_code(const CsgIter &it) { return it.tag | (it.leaf << 3) | ((it.leaf_exit ? 1u : 0u) << 6); }
 
 // LEAN: the kernel is short of registers (texture code next to the intersection code), so a volume
 // over a primitive goes through the general event walk instead of its own few lines.
-template <bool SIMPLE, bool MOTION = false, bool LEAN = false>
+// UNI: `ref` is the same in every lane (the list traversal), so the object's records are read once per wave.
+template <bool SIMPLE, bool MOTION = false, bool LEAN = false, bool UNI = false>
 RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmin, float tmax, uint64_t volume_key,
                         const float *scripted, uint32_t n_scripted, bool &found, Best &best, float time = 0.0f) {
     uint32_t kind = (ref >> RT_KIND_SHIFT) & 7u, idx = ref & RT_INDEX_MASK;
@@ -522,10 +555,20 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
         idx = ref & RT_INDEX_MASK;
     }
     if (SIMPLE) {
-        Span sp = sphere_span(s, idx, o, d);
+        Span sp = sphere_span<UNI>(s, idx, o, d);
         if (span_valid(sp)) {
             if (in_range(sp.t0, tmin, tmax, found, best.t)) { best.t = sp.t0; best.ref = self; best.code = 0; found = true; }
             else if (in_range(sp.t1, tmin, tmax, found, best.t)) { best.t = sp.t1; best.ref = self; best.code = 0; found = true; }
+        }
+        return;
+    }
+    if (UNI && kind <= RT_KIND_QUAD) {
+        // the list traversal knows the kind per wave: a plain primitive is tested directly, without
+        // setting up the interval walk (which costs as much as a quad test)
+        Span sp = prim_span<UNI>(s, ref, o, d);
+        if (span_valid(sp)) {
+            if (in_range(sp.t0, tmin, tmax, found, best.t)) { best.t = sp.t0; best.ref = self; best.code = sp.tag0; found = true; }
+            else if (in_range(sp.t1, tmin, tmax, found, best.t)) { best.t = sp.t1; best.ref = self; best.code = sp.tag1; found = true; }
         }
         return;
     }
@@ -535,12 +578,18 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
     uint32_t shape = ref;
     float neg_inv_density = 0.0f;
     if (volume) {
-        const RtDevCdv cv = s.cdv[idx];
+        const RtDevCdv cv = ld<UNI && !MOTION>(s.cdv + idx);
         shape = cv.base;
         neg_inv_density = cv.neg_inv_density;
+        if (UNI && ((shape >> RT_KIND_SHIFT) & 7u) != RT_KIND_CSG) {
+            Span sp = prim_span<UNI>(s, shape, o, d);
+            if (span_valid(sp))
+                volume_over_primitive<UNI>(s, idx, self, sp.t0, sp.t1, sp.tag0, sp.tag1, neg_inv_density, tmin, tmax, volume_key, scripted, found, best);
+            return;
+        }
     }
     CsgIter it;
-    csg_begin(s, shape, o, d, it);
+    csg_begin<UNI>(s, shape, o, d, it);
     if (!volume) {
         if (kind <= RT_KIND_QUAD) {
             // one interval: entry, else exit (Shaders.metal:182-199 on a two-hit enumerator)
@@ -567,16 +616,8 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
     if (!LEAN && ((shape >> RT_KIND_SHIFT) & 7u) != RT_KIND_CSG) {
         // a primitive base has one interval: no event walk needed
         if (it.entered & 1u) return;
-        const float t1 = fmaxf(0.0f, it.tin[0]), t2 = it.tout[0];
-        if (!(t1 < t2)) return;
-        if (found && best.t <= t1) return;      // nothing inside the medium can beat the current hit
-        float u;
-        if (scripted) u = scripted[0];
-        else { Pcg vr = pcg_seed(volume_key, (uint64_t)(s.cdv_obj[idx] + 1u)); u = rnd(vr); }
-        const float t = fmaf(logf(1.0f - u), neg_inv_density, t1);
-        if (!(t <= t2)) return;
-        if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = self; best.code = RT_CODE_SCATTER | ((uint32_t)it.tags & 7u); found = true; }
-        else if (in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = self; best.code = ((uint32_t)it.tags >> 3) & 7u; found = true; }
+        volume_over_primitive<UNI>(s, idx, self, it.tin[0], it.tout[0], (uint32_t)it.tags & 7u, ((uint32_t)it.tags >> 3) & 7u, neg_inv_density,
+                                   tmin, tmax, volume_key, scripted, found, best);
         return;
     }
     Pcg vr;

@@ -110,6 +110,7 @@ struct RtScene {
     uint32_t refill = 48;
     int node_min = -1;      // -1: chosen at render time from what the scene holds
     int heavy_min = -1;     // -1: default
+    int traversal = RT_TRAVERSAL_AUTO;
     int node_format = RT_NODES_AUTO;
     int convention = RT_CONVENTION_METAL;
     bool profile_phases = false;
@@ -1105,6 +1106,20 @@ int rt_scene_commit(RtScene *sc) {
     if ((rc = upload(sc, sc->perlin, &d.perlin)) < 0) return rc;
     if ((rc = upload(sc, sc->kit_textures, &d.kit_textures)) < 0) return rc;
     if ((rc = upload(sc, sc->kit_perlin, &d.kit_perlin)) < 0) return rc;
+    if (!bld.items.empty() && bld.items.size() <= RT_LINEAR_MAX) {
+        // Array<any Hittable>.hit of RayTracingKit/Hittable.swift:662-671: the plain list of objects
+        std::vector<uint32_t> list(8 * bld.items.size(), 0u);
+        for (size_t i = 0; i < bld.items.size(); i++) {
+            const BuildItem &it = bld.items[i];
+            list[8 * i] = it.ref;
+            for (int a = 0; a < 3; a++) {
+                memcpy(&list[8 * i + 1 + 2 * a], &it.box.mn[a], 4);
+                memcpy(&list[8 * i + 2 + 2 * a], &it.box.mx[a], 4);
+            }
+        }
+        if ((rc = upload(sc, list, &d.object_list)) < 0) return rc;
+        d.n_listed = (uint32_t)bld.items.size();
+    }
     d.root = root;
     d.n_nodes = (uint32_t)(bld.nodes.size() / 16);
     d.kit_convention = sc->convention == RT_CONVENTION_KIT ? 1u : 0u;
@@ -1132,7 +1147,9 @@ int rt_scene_commit(RtScene *sc) {
         RtDevRender r{};
         r.band_count = 1;
         (void)rt_render_fused(sc->dev, sc->feat, st.bvh_depth, cam, r, sc->use_nodes16 ? 0x20000u : 0u, nullptr, nullptr, 0, nullptr,
-                              nullptr, sc->ctx->cus, true);
+                              nullptr, sc->ctx->cus, true, 0u);
+        (void)rt_render_fused(sc->dev, sc->feat, st.bvh_depth, cam, r, sc->use_nodes16 ? 0x20000u : 0u, nullptr, nullptr, 0, nullptr,
+                              nullptr, sc->ctx->cus, true, 0x100u);
     }
     return RT_OK;
 }
@@ -1161,6 +1178,10 @@ int rt_scene_set_option(RtScene *sc, int option, int value) {
     case RT_OPTION_HEAVY_MIN:
         if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "heavy minimum must be 0..64");
         sc->heavy_min = value;
+        return RT_OK;
+    case RT_OPTION_TRAVERSAL:
+        if (value != RT_TRAVERSAL_AUTO && value != RT_TRAVERSAL_TREE && value != RT_TRAVERSAL_LIST) return fail(RT_ERR_INVALID, "unknown traversal");
+        sc->traversal = value;
         return RT_OK;
     case RT_OPTION_KERNEL_TIMING:
         if (!value) sc->timer.collect();
@@ -1270,7 +1291,10 @@ uint32_t fused_knobs(const RtScene *sc, const RtDevCamera &cam) {
            ((cam.defocus ? 16u : 0u) << 18) | (((sc->feat & 1u) ? 65u : 20u) << 25);
 }
 
-uint32_t fused_knobs2(const RtScene *sc) { return sc->heavy_min >= 0 ? (uint32_t)sc->heavy_min : RT_DEFAULT_HEAVY_MIN; }
+uint32_t fused_knobs2(const RtScene *sc) {
+    const uint32_t heavy = sc->heavy_min >= 0 ? (uint32_t)sc->heavy_min : RT_DEFAULT_HEAVY_MIN;
+    return heavy | (sc->traversal == RT_TRAVERSAL_TREE ? 0x100u : 0u);
+}
 
 int render_checks(const RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, const float *accum_dev, int width, int height) {
     if (!sc || !cc || !rc || !accum_dev || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "bad argument");

@@ -501,7 +501,10 @@ __global__ void k_fused_setup(uint32_t *workspace, RtDevCamera cam) {
 // shapes or volumes at 4 (128 VGPRs: at 96 their leaf tests spill and run at half the rate).
 // DEEP: the tree may be deeper than STACK; entries from STACK up live in global memory behind
 // the workspace header (RT_FUSED_DEEP_OFFSET), one column per thread of the grid.
-template <int FEAT, bool PROF, int STACK, int WPS, bool NODE16, bool DEEP = false>
+// LIST: the scene is small enough to carry its objects as a plain list (RtDevScene::object_list);
+// the extend phase then tests object 0, 1, 2 ... in turn, the same object in every lane: no tree, no
+// stack, no divergence between kinds of object, and every lane with a path takes part.
+template <int FEAT, bool PROF, int STACK, int WPS, bool NODE16, bool DEEP = false, bool LIST = false>
 __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtDevCamera *camp, uint32_t background, RtDevRender rc, float *accum,
                                                      uint32_t *counter, uint32_t n_items, uint32_t tiles_x,
                                                      uint32_t n_tiles, uint32_t chunk_spp, uint32_t knobs, uint32_t heavy_min) {
@@ -652,6 +655,36 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
             continue;
         }
         // ---- extend phase
+        if (LIST) {
+            // Array<any Hittable>.hit, RayTracingKit/Hittable.swift:662-671: closest hit over the list,
+            // the range shrinking as hits are found.  The object is the same in all lanes (its record
+            // comes through scalar loads); boxes are only tested where the object's own test costs more.
+            RT_PROF_BEGIN();
+            const bool walking = t.cur != RT_REF_NONE;
+            const uint32_t n_listed = s.n_listed;
+            for (uint32_t k = 0; k < n_listed; k++) {
+                const __attribute__((address_space(4))) uint32_t *rec =
+                    (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)(s.object_list + 8u * k);
+                const uint32_t ref = rec[0];
+                const uint32_t okind = (ref >> RT_KIND_SHIFT) & 7u;
+                bool wanted = walking;
+                if (okind != RT_KIND_SPHERE && okind != RT_KIND_QUAD) {
+                    const float x0 = __uint_as_float(rec[1]), x1 = __uint_as_float(rec[2]), y0 = __uint_as_float(rec[3]);
+                    const float y1 = __uint_as_float(rec[4]), z0 = __uint_as_float(rec[5]), z1 = __uint_as_float(rec[6]);
+                    v2f tx = {fmaf(x0, t.inv_d.x, t.oid.x), fmaf(x1, t.inv_d.x, t.oid.x)};
+                    v2f ty = {fmaf(y0, t.inv_d.y, t.oid.y), fmaf(y1, t.inv_d.y, t.oid.y)};
+                    v2f tz = {fmaf(z0, t.inv_d.z, t.oid.z), fmaf(z1, t.inv_d.z, t.oid.z)};
+                    bool in_box;
+                    (void)box_entry(tx, ty, tz, RT_T_MIN, t.best.t, in_box);
+                    wanted = wanted && in_box;
+                }
+                if (wanted)
+                    test_object<SIMPLE, (FEAT & RT_FEAT_MOTION) != 0, (FEAT & RT_FEAT_TEXTURE) != 0, true>(s, ref, t.o, t.d, RT_T_MIN, RT_INF, key, nullptr, 0, t.found, t.best, time);
+            }
+            if (walking) t.cur = RT_REF_NONE;
+            RT_PROF_END(3, walking);
+            continue;
+        }
         while (true) {
             // node steps go on while enough lanes sit on inner nodes; once fewer than
             // node_min do and some lane waits at a leaf, or leaf_max lanes wait there, the
@@ -867,7 +900,7 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
     return hipSuccess;
 }
 
-template <int FEAT, int STACK, int WPS, bool NODE16, bool DEEP = false>
+template <int FEAT, int STACK, int WPS, bool NODE16, bool DEEP = false, bool LIST = false>
 static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, const RtDevRender &rc, float *accum,
                                uint32_t *counter, uint32_t knobs, uint32_t knobs2, hipStream_t stream, RtKernelTimer *timer, int cus,
                                bool prepare_only) {
@@ -883,7 +916,7 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     (void)hipGetDevice(&dev);
     int occ = (dev >= 0 && dev < 64) ? occ_of_device[dev] : 0;
     if (occ < 1) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS, NODE16, DEEP>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS, NODE16, DEEP, LIST>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
         if (dev >= 0 && dev < 64) occ_of_device[dev] = occ;
     }
     if (prepare_only) return hipSuccess;
@@ -909,9 +942,9 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     const RtDevCamera *camp = (const RtDevCamera *)((const char *)counter + RT_FUSED_CAMERA_OFFSET);
     if (timer) timer->begin(stream);
     if (prof)
-        k_fused<FEAT, true, STACK, WPS, NODE16, DEEP><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u));
+        k_fused<FEAT, true, STACK, WPS, NODE16, DEEP, LIST><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u));
     else
-        k_fused<FEAT, false, STACK, WPS, NODE16, DEEP><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u));
+        k_fused<FEAT, false, STACK, WPS, NODE16, DEEP, LIST><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u));
     if (timer) timer->end(stream);
     return hipGetLastError();
 }
@@ -928,6 +961,19 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
     const bool n16 = (knobs & 0x20000u) != 0 && s.nodes16 != nullptr;
 #define RT_FUSED(F, ST, W) (n16 ? fused_launch<F, ST, W, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only) \
                                 : fused_launch<F, ST, W, false>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only))
+    if (s.object_list && s.n_listed && !(knobs2 & 0x100u)) {
+        // a handful of objects: the list, not the tree (one stack entry is declared and never used)
+#define RT_FUSED_LIST(F, W) fused_launch<F, 1, W, false, false, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only)
+        switch (feat & 7u) {
+        case 0: return RT_FUSED_LIST(0, RT_WPS0);
+        case 1: return RT_FUSED_LIST(1, 4);
+        case 2: return RT_FUSED_LIST(2, 5);
+        case 3: return RT_FUSED_LIST(3, 4);
+        case 5: return RT_FUSED_LIST(5, 4);
+        default: return RT_FUSED_LIST(7, 4);
+        }
+#undef RT_FUSED_LIST
+    }
     switch (feat & 7u) {
     case 0:
         if (bvh_depth <= 16) return RT_FUSED(0, 16, RT_WPS0);

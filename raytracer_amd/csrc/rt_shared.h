@@ -40,6 +40,7 @@ enum RtPrimKind : uint32_t {
 // the fused workspace all follow this one definition.
 #define RT_STACK_DEPTH 24
 #define RT_BLOCK 256             // threads per workgroup of every traversal kernel
+#define RT_LINEAR_MAX 16         // scenes up to this many objects are rendered without a tree
 #define RT_CSG_LEAVES 8
 
 static inline uint32_t rt_make_ref(uint32_t kind, uint32_t index) { return (kind << RT_KIND_SHIFT) | index; }
@@ -120,6 +121,12 @@ struct RtDevScene {
     const RtDevPerlin *perlin;
     const RtDevKitTexture *kit_textures;
     const RtDevKitPerlin *kit_perlin;
+    // Scenes of at most RT_LINEAR_MAX objects also carry their objects as a plain list (reference and
+    // padded box, 8 words per object: ref, 6 planes min/max per axis, pad): the render kernel then
+    // tests every object in turn, the same object in all lanes at once, instead of walking a tree.
+    const uint32_t *object_list;
+    uint32_t n_listed;             // 0 when there is no list
+    uint32_t pad0;
     uint32_t root;                 // child reference of the root (RT_REF_NONE for an empty scene)
     uint32_t n_nodes;
     uint32_t kit_convention;       // 1: RayTracingKit's texture coordinates and metal rule (RT_CONVENTION_KIT)

@@ -208,7 +208,7 @@ class Renderer:
 
     def __init__(self, scene, width, height, pipeline=abi.RT_PIPELINE_FUSED, device_ordinal=0, ctx=None, dedup=True,
                  bvh=abi.RT_BVH_SAH, refill=None, node_min=None, nodes=abi.RT_NODES_AUTO, timing=False, profile_phases=False,
-                 bands=None, native=None, heavy_min=None):
+                 bands=None, native=None, heavy_min=None, traversal=None):
         """`native`: an already committed NativeScene of `scene` to render from (a large scene is
         flattened and its tree built once, then shared by several renderers)."""
         self.ctx = ctx or (native.ctx if native is not None else Context(device_ordinal))
@@ -225,6 +225,8 @@ class Renderer:
             self.native.set_option(abi.RT_OPTION_NODE_MIN, node_min)
         if heavy_min is not None:
             self.native.set_option(abi.RT_OPTION_HEAVY_MIN, heavy_min)
+        if traversal is not None:
+            self.native.set_option(abi.RT_OPTION_TRAVERSAL, traversal)
         if timing:
             self.native.set_option(abi.RT_OPTION_KERNEL_TIMING, 1)
         if profile_phases:

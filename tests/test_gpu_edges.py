@@ -126,6 +126,40 @@ def test_half_precision_nodes_render_the_same_image(ctx, make):
     assert close > 0.999          # a path that meets an exact tie between two objects may take the other one
 
 
+@pytest.mark.parametrize("name", ["simpleBalls", "singleCylinder", "texturedCylinders", "pencilInGlass", "compositionDemo", "quads",
+                                  "world1", "cornell", "moving"])
+def test_list_and_tree_traversal_render_the_same_image(ctx, name):
+    """Scenes of at most 16 objects are rendered from the plain object list (every lane tests the same
+    object, RayTracingKit/Hittable.swift:662-671) instead of the tree: same closest hits, so the same
+    image up to the order of the float sums; a path that meets two objects at exactly the same distance
+    may take the other one."""
+    from raytracer_amd.renderer import Renderer
+    if name == "cornell":
+        scene = scenes.cornell_smoke()
+    elif name == "moving":
+        from raytracer_amd.scene import MotionBlur
+        m = ColoredLambertian((0.7, 0.4, 0.3))
+        scene = Scene(CameraConfig(vertical_fov=40, look_from=(0, 1, 6), look_at=(0, 0, 0)), [
+            Sphere((0, -100.5, 0), 100, ColoredLambertian((0.5, 0.5, 0.5))),
+            MotionBlur(T.translate(0, 0.8, 0), Sphere((-1.2, 0, 0), 0.5, m)),
+            MotionBlur(T.rotation_deg(60, "y"), Cuboid(T.translate(0.6, -0.5, -0.4), (0.9, 0.9, 0.8), m))])
+    else:
+        scene = scenes.DEMO_SCENES[name]()
+    imgs = []
+    for traversal in (abi.RT_TRAVERSAL_TREE, abi.RT_TRAVERSAL_LIST):
+        r = Renderer(scene, 200, 120, ctx=ctx, traversal=traversal)
+        assert 1 <= r.native.stats()["n_objects"] <= 16
+        r.draw(8, 20, 11)
+        torch.cuda.synchronize()
+        imgs.append(r.accum.clone())
+    a, b = imgs
+    assert torch.isfinite(b).all() and b.sum().item() > 0
+    scale = max(1.0, a.abs().max().item())
+    close = ((a - b).abs() <= 1e-4 * scale).float().mean().item()
+    print(name, "pixels equal to 1e-4:", close)
+    assert close > 0.999
+
+
 @pytest.mark.parametrize("size,spp", [((37, 19), 1), ((5, 3), 7), ((64, 8), 3), ((131, 77), 33)])
 def test_ragged_images_and_odd_sample_counts(ctx, size, spp):
     """Partial 8x8 tiles, fewer pixels than one tile, sample counts that do not divide into
