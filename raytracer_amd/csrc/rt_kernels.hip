@@ -973,11 +973,13 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
 #define RT_FUSED(F, ST, W) (n16 ? fused_launch<F, ST, W, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only) \
                                 : fused_launch<F, ST, W, false>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only))
     if (s.object_list && s.n_listed && !(knobs2 & 0x100u)) {
-        // a handful of objects: the list, not the tree (one stack entry is declared and never used)
+        // a handful of objects: the list, not the tree (one stack entry is declared and never used).  Untextured
+        // scenes run 5 waves per SIMD: 96 registers and 20 spilled ones beat 107 registers at 4 waves by 5 % (6 waves: -1 %);
+        // with texture code next to it the same trade loses (-13 % on the Kit's second world)
 #define RT_FUSED_LIST(F, W) fused_launch<F, 1, W, false, false, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only)
         switch (feat & 7u) {
         case 0: return RT_FUSED_LIST(0, RT_WPS0);
-        case 1: return RT_FUSED_LIST(1, 4);
+        case 1: return RT_FUSED_LIST(1, 5);
         case 2: return RT_FUSED_LIST(2, 5);
         case 3: return RT_FUSED_LIST(3, 4);
         case 5: return RT_FUSED_LIST(5, 4);
