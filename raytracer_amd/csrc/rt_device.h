@@ -484,23 +484,29 @@ RT_DEV bool csg_next(const RtDevScene &s, CsgIter &it) {
 // The frame of a moving object at `time`: transform.pow(time) = (rotation^time, time *
 // translation), RayTracingKit/Transform.swift:82-84,243-250.  Rays go into the frame
 // (Hittable.swift:578-592), normals come back out (:70-73); t is the same on both sides.
-struct MotionFrame { f3 c0, c1, c2, t; uint32_t base; };
+struct MotionFrame { f3 c0, c1, c2, t; uint32_t base; bool rotates; };
 RT_DEV MotionFrame motion_frame(const RtDevScene &s, uint32_t idx, float time) {
     const RtDevMotion m = s.motion[idx];
-    float a = m.half_angle * time;
-    float w = cosf(a), k = sinf(a) * m.inv_sin;
-    float x = m.qx * k, y = m.qy * k, z = m.qz * k;
     MotionFrame f;
-    // columns of the rotation matrix of the unit quaternion (w, x, y, z)
-    f.c0 = mk3(1.0f - 2.0f * (y * y + z * z), 2.0f * (x * y + w * z), 2.0f * (x * z - w * y));
-    f.c1 = mk3(2.0f * (x * y - w * z), 1.0f - 2.0f * (x * x + z * z), 2.0f * (y * z + w * x));
-    f.c2 = mk3(2.0f * (x * z + w * y), 2.0f * (y * z - w * x), 1.0f - 2.0f * (x * x + y * y));
     f.t = mk3(m.tx * time, m.ty * time, m.tz * time);
     f.base = m.base;
+    // a pure translation (inv_sin = 0: the identity rotation) needs no sine, cosine or matrix:
+    // multiplying by the identity changes no bit of a vector
+    f.rotates = m.inv_sin != 0.0f;
+    f.c0 = mk3(1, 0, 0); f.c1 = mk3(0, 1, 0); f.c2 = mk3(0, 0, 1);
+    if (f.rotates) {
+        float a = m.half_angle * time;
+        float w = cosf(a), k = sinf(a) * m.inv_sin;
+        float x = m.qx * k, y = m.qy * k, z = m.qz * k;
+        // columns of the rotation matrix of the unit quaternion (w, x, y, z)
+        f.c0 = mk3(1.0f - 2.0f * (y * y + z * z), 2.0f * (x * y + w * z), 2.0f * (x * z - w * y));
+        f.c1 = mk3(2.0f * (x * y - w * z), 1.0f - 2.0f * (x * x + z * z), 2.0f * (y * z + w * x));
+        f.c2 = mk3(2.0f * (x * z + w * y), 2.0f * (y * z - w * x), 1.0f - 2.0f * (x * x + y * y));
+    }
     return f;
 }
-RT_DEV f3 frame_in(const MotionFrame &f, f3 v) { return mk3(dot(f.c0, v), dot(f.c1, v), dot(f.c2, v)); }
-RT_DEV f3 frame_out(const MotionFrame &f, f3 v) { return madd(f.c0, v.x, madd(f.c1, v.y, f.c2 * v.z)); }
+RT_DEV f3 frame_in(const MotionFrame &f, f3 v) { return f.rotates ? mk3(dot(f.c0, v), dot(f.c1, v), dot(f.c2, v)) : v; }
+RT_DEV f3 frame_out(const MotionFrame &f, f3 v) { return f.rotates ? madd(f.c0, v.x, madd(f.c1, v.y, f.c2 * v.z)) : v; }
 
 // ------------------------------------------------------------------ closest hit of one object
 // What extend remembers about the closest hit; `code` lets shade rebuild the surface:

@@ -1014,8 +1014,12 @@ int rt_scene_commit(RtScene *sc) {
         it.ref = s.ref;
         it.box = shape_box(*sc, sc->objects[o]);
         pad_box(it.box);
-        if (s.kind != RT_KIND_SPHERE) feat |= RT_FEAT_XPRIM;
-        if (s.kind == RT_KIND_MOTION) feat |= RT_FEAT_MOTION;
+        if (s.kind == RT_KIND_MOTION) {
+            feat |= RT_FEAT_MOTION;
+            if (sc->shapes[s.base].kind != RT_KIND_SPHERE) feat |= RT_FEAT_XPRIM;
+        } else if (s.kind != RT_KIND_SPHERE) {
+            feat |= RT_FEAT_XPRIM;
+        }
         bld.items.push_back(it);
     }
     for (size_t i = 0; i < n_bulk; i++) {

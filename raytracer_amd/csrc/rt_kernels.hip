@@ -22,6 +22,9 @@
 
 #define RT_WPS0 8              // waves per SIMD of the spheres-only kernel (64 VGPRs)
 #define RT_WPS_DEEP 7          // ... of its deep-tree form: 72 VGPRs, measured +5 % on the million-sphere workload over 8 (6: +-0)
+#ifndef RT_WPS_MOVING_SPHERES
+#define RT_WPS_MOVING_SPHERES 6   // ... of the spheres-and-moving-spheres kernel
+#endif
 #define RT_DOUBLE_STEP 24u       // lanes on inner nodes from which a second node step follows the first without a new count (+1.6 % on random spheres)
 #define RT_T_MIN 1e-3f          // Camera.swift:117
 #define RT_WAVES (RT_BLOCK / 64)
@@ -300,19 +303,31 @@ RT_DEV bool shade_path(const RtDevScene &s, uint32_t background, uint32_t max_de
     if (!(FEAT & RT_FEAT_XPRIM)) {
         // spheres only: geometry and the sphere's own copy of its material record are
         // independent loads (one memory round trip)
-        uint32_t idx = b.ref & RT_INDEX_MASK;
+        // A moving sphere (scenes of spheres and moving spheres only) is its base sphere seen from
+        // the frame of its transform at the sample's time; the normal comes back out of the frame.
+        uint32_t ref = b.ref;
+        f3 fo = o, fd = d;
+        MotionFrame frame;
+        const bool moving = (FEAT & RT_FEAT_MOTION) && kind == RT_KIND_MOTION;
+        if ((FEAT & RT_FEAT_MOTION) && moving) {
+            frame = motion_frame(s, b.ref & RT_INDEX_MASK, time);
+            fo = frame_in(frame, o - frame.t);
+            fd = frame_in(frame, d);
+            ref = frame.base;
+        }
+        uint32_t idx = ref & RT_INDEX_MASK;
         float4 g4 = ((const float4 *)s.spheres)[idx];
         const float4 *mr = (const float4 *)s.sphere_mrec + 2u * idx;
         float4 m0 = mr[0], m1 = mr[1];
         m = unpack_material(m0, m1);
         h.point = madd(d, b.t, o);
-        f3 n = (h.point - mk3(g4.x, g4.y, g4.z)) * rcp(g4.w);
+        f3 n = (madd(fd, b.t, fo) - mk3(g4.x, g4.y, g4.z)) * rcp(g4.w);
+        if ((FEAT & RT_FEAT_MOTION) && moving) n = frame_out(frame, n);
         h.material = 0;
         h.u = h.v = 0.f;
         if (dot(n, d) > 0.f) { h.normal = -n; h.front = false; } else { h.normal = n; h.front = true; }
-        (void)kind;
         if (maybe_uv && material_wants_uv(m.kind)) {
-            Surface sf = prim_surface(s, b.ref, 0, o, d, b.t, true);
+            Surface sf = prim_surface(s, ref, 0, fo, fd, b.t, true);
             h.u = sf.u; h.v = sf.v;
         }
     } else {
@@ -982,7 +997,7 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
         case 1: return RT_FUSED_LIST(1, 5);
         case 2: return RT_FUSED_LIST(2, 5);
         case 3: return RT_FUSED_LIST(3, 4);
-        case 5: return RT_FUSED_LIST(5, 4);
+        case 4: case 5: return RT_FUSED_LIST(5, 4);
         default: return RT_FUSED_LIST(7, 4);
         }
 #undef RT_FUSED_LIST
@@ -1001,6 +1016,10 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
     case 1: return RT_FUSED(1, RT_STACK_DEPTH, 4);
     case 2: return RT_FUSED(2, RT_STACK_DEPTH, 5);
     case 3: return RT_FUSED(3, RT_STACK_DEPTH, 4);
+    case 4:
+        // spheres and moving spheres only: the spheres kernel with the frame change in front of its sphere test
+        if (bvh_depth <= 16) return RT_FUSED(4, 16, RT_WPS_MOVING_SPHERES);
+        return RT_FUSED(5, RT_STACK_DEPTH, 4);
     case 5: return RT_FUSED(5, RT_STACK_DEPTH, 4);
     default: return RT_FUSED(7, RT_STACK_DEPTH, 4);
     }

@@ -12,9 +12,9 @@
 
 // Scene features that select a kernel specialisation.
 enum : uint32_t {
-    RT_FEAT_XPRIM = 1u,      // anything other than plain spheres in the BVH
+    RT_FEAT_XPRIM = 1u,      // anything other than plain spheres and moving plain spheres in the BVH
     RT_FEAT_TEXTURE = 2u,    // image or Perlin materials
-    RT_FEAT_MOTION = 4u,     // moving objects: every sample draws a time (implies RT_FEAT_XPRIM)
+    RT_FEAT_MOTION = 4u,     // moving objects: every sample draws a time
 };
 
 // HIP events around every launch of the render loop's dominant kernel, on the stream the
