@@ -187,7 +187,7 @@ enum RtPipeline {
     RT_PIPELINE_FUSED = 1,       /* one persistent kernel, the stages as wave-wide phases, paths regenerated in place */
 };
 
-#define RT_CSG_MAX_LEAVES 8      /* leaf primitives under one CSG object */
+#define RT_CSG_MAX_LEAVES 64     /* leaf primitives under one CSG object (up to 8 are walked from registers, more by recomputation) */
 #define RT_MAX_EVENTS 16         /* boundary crossings rt_intervals can report per ray */
 
 typedef struct RtContext RtContext;

@@ -10,7 +10,7 @@ RT_PIPELINE_WAVEFRONT, RT_PIPELINE_FUSED = 0, 1
 RT_OPTION_BVH_BUILDER, RT_OPTION_REFILL_THRESHOLD, RT_OPTION_NODE_MIN, RT_OPTION_NODE_FORMAT = 1, 2, 3, 4
 RT_NODES_AUTO, RT_NODES_F32, RT_NODES_F16 = 0, 1, 2
 RT_BVH_MEDIAN_SPLIT, RT_BVH_SAH = 0, 1
-RT_CSG_MAX_LEAVES = 8
+RT_CSG_MAX_LEAVES = 64
 RT_MAX_EVENTS = 16
 RT_PERLIN_TABLE_SIZE = 256
 

@@ -480,6 +480,96 @@ RT_DEV bool csg_next(const RtDevScene &s, CsgIter &it) {
     }
 }
 
+// A shape of more than RT_CSG_LEAVES leaves (up to 64) is walked with the same rule and the same tie order, but
+// nothing per leaf is kept: every step computes the leaves' intervals again and evaluates the shape's expression
+// (a postfix program over "inside leaf i" bits) instead of looking a table up.  A step costs as many interval
+// tests as the shape has leaves; the state is two 64-bit masks.  Such shapes are rare (the reference's scenes stop
+// at five leaves); kernels only look for them in scenes that hold one (RtDevScene::n_wide_csg).
+struct WideIter {
+    f3 o, d;
+    const uint32_t *leaves, *tokens;
+    uint32_t n, n_tokens;
+    uint64_t entered, exited;
+    bool inside;
+    // current event
+    float t;
+    uint32_t leaf, tag;
+    bool is_exit, leaf_exit;
+};
+
+RT_DEV bool is_wide_csg(const RtDevScene &s, uint32_t shape) {
+    return s.n_wide_csg != 0u && ((shape >> RT_KIND_SHIFT) & 7u) == RT_KIND_CSG && s.csg[shape & RT_INDEX_MASK].n_leaves > RT_CSG_LEAVES;
+}
+
+RT_DEV bool wide_inside(const WideIter &it, uint64_t mask) {
+    uint64_t st = 0;                 // a stack of bits, top in bit 0
+    for (uint32_t i = 0; i < it.n_tokens; i++) {
+        const uint32_t tok = it.tokens[i];
+        if (tok < 64u) { st = (st << 1) | ((mask >> tok) & 1u); continue; }
+        const uint64_t b = st & 1u, a = (st >> 1) & 1u;
+        const uint64_t r = tok == RT_CSG_TOKEN_UNION ? (a | b) : (tok == RT_CSG_TOKEN_INTERSECTION ? (a & b) : (a & ~b & 1u));
+        st = ((st >> 2) << 1) | r;
+    }
+    return st & 1u;
+}
+
+RT_DEV void csg_begin_wide(const RtDevScene &s, uint32_t shape, f3 o, f3 d, WideIter &it) {
+    const RtDevCsg &c = s.csg[shape & RT_INDEX_MASK];
+    const uint32_t *rec = s.csg_pool + c.leaf[0];
+    it.o = o; it.d = d;
+    it.n = c.n_leaves;
+    it.n_tokens = rec[2];
+    it.leaves = rec + RT_CSG_POOL_HEADER;
+    it.tokens = it.leaves + it.n;
+    it.entered = it.exited = 0;
+    it.inside = wide_inside(it, 0);
+    it.t = 0.f; it.leaf = it.tag = 0; it.is_exit = it.leaf_exit = false;
+}
+
+RT_DEV bool csg_next(const RtDevScene &s, WideIter &it) {
+    while (true) {
+        float best = RT_INF;
+        int who = -1;
+        uint32_t tag = 0;
+        for (int j = (int)it.n - 1; j >= 0; j--) {
+            if ((it.exited >> j) & 1u) continue;
+            const Span sp = prim_span(s, it.leaves[j], it.o, it.d);
+            if (!span_valid(sp)) { it.entered |= 1ull << j; it.exited |= 1ull << j; continue; }     // nothing to visit
+            const bool ent = (it.entered >> j) & 1u;
+            const float cand = ent ? sp.t1 : sp.t0;
+            if (cand < best) { best = cand; who = j; tag = ent ? sp.tag1 : sp.tag0; }
+        }
+        if (who < 0) return false;
+        const bool leaf_exit = (it.entered >> who) & 1u;
+        if (leaf_exit) it.exited |= 1ull << who; else it.entered |= 1ull << who;
+        const bool now = wide_inside(it, it.entered & ~it.exited);
+        if (now != it.inside) {
+            it.inside = now;
+            it.t = best;
+            it.leaf = (uint32_t)who;
+            it.leaf_exit = leaf_exit;
+            it.is_exit = !now;
+            it.tag = tag;
+            return true;
+        }
+    }
+}
+
+// Leaf `leaf` of a CSG shape and whether its normals are turned round (it sits under an odd number of
+// subtracted operands, RenderableImpl.h:712).
+template <bool WIDE = true>
+RT_DEV uint32_t csg_leaf(const RtDevScene &s, uint32_t csg_idx, uint32_t leaf, bool &flip) {
+    const RtDevCsg &c = s.csg[csg_idx];
+    if (WIDE && s.n_wide_csg != 0u && c.n_leaves > RT_CSG_LEAVES) {
+        const uint32_t *rec = s.csg_pool + c.leaf[0];
+        const uint64_t flips = rec[0] | ((uint64_t)rec[1] << 32);
+        flip = (flips >> leaf) & 1u;
+        return rec[RT_CSG_POOL_HEADER + leaf];
+    }
+    flip = (c.flip_mask >> leaf) & 1u;
+    return c.leaf[leaf & (RT_CSG_LEAVES - 1u)];
+}
+
 // ------------------------------------------------------------------ motion blur
 // The frame of a moving object at `time`: transform.pow(time) = (rotation^time, time *
 // translation), RayTracingKit/Transform.swift:82-84,243-250.  Rays go into the frame
@@ -511,13 +601,19 @@ RT_DEV f3 frame_out(const MotionFrame &f, f3 v) { return f.rotates ? madd(f.c0, 
 // ------------------------------------------------------------------ closest hit of one object
 // What extend remembers about the closest hit; `code` lets shade rebuild the surface:
 //   primitive        tag
-//   CSG              tag | leaf << 3 | leaf_exit << 6
+//   CSG              tag | (leaf & 7) << 3 | leaf_exit << 6 | (leaf >> 3) << 28 (only wide shapes have leaves beyond 7)
 //   volume (CDV)     bit 31 set = scatter inside the medium; low bits = the base's code for
 //                    the entry event (scatter) or the exit event (boundary)
 struct Best { float t; uint32_t ref, code; };
 
 #define RT_CODE_SCATTER 0x80000000u
-#define RT_CODE_INTERVAL_SHIFT 8
+#define RT_CODE_LEAF_EXIT_SHIFT 6
+#define RT_CODE_INTERVAL_SHIFT 8        // the volume's interval counter: bits 8..27
+#define RT_CODE_LEAF_HIGH_SHIFT 28
+template <bool WIDE>
+RT_DEV uint32_t code_leaf(uint32_t code) {
+    return ((code >> 3) & 7u) | (WIDE ? ((code >> RT_CODE_LEAF_HIGH_SHIFT) & 7u) << 3 : 0u);
+}
 
 // Accept rule of Shaders.metal:182-199 for one candidate distance.
 RT_DEV bool in_range(float t, float tmin, float tmax_incl, bool found, float best) {
@@ -542,12 +638,64 @@ RT_DEV void volume_over_primitive(const RtDevScene &s, uint32_t cdv_idx, uint32_
     else if (in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = self; best.code = tag_out; found = true; }
 }
 
-RT_DEV uint32_t event_code(const CsgIter &it) { return it.tag | (it.leaf << 3) | ((it.leaf_exit ? 1u : 0u) << 6); }
+RT_DEV uint32_t event_code(const CsgIter &it) { return it.tag | (it.leaf << 3) | ((it.leaf_exit ? 1u : 0u) << RT_CODE_LEAF_EXIT_SHIFT); }
+template <class It>
+RT_DEV uint32_t event_code(const It &it) {
+    return it.tag | ((it.leaf & 7u) << 3) | ((it.leaf_exit ? 1u : 0u) << RT_CODE_LEAF_EXIT_SHIFT) | ((it.leaf >> 3) << RT_CODE_LEAF_HIGH_SHIFT);
+}
+
+// First boundary of a shape that is an acceptable hit (Shaders.metal:182-199 on the shape's event list).
+template <class It>
+RT_DEV void walk_boundary(const RtDevScene &s, It &it, uint32_t self, float tmin, float tmax, bool &found, Best &best) {
+    while (csg_next(s, it)) {
+        if (in_range(it.t, tmin, tmax, found, best.t)) {
+            best.t = it.t; best.ref = self;
+            best.code = event_code(it);
+            found = true;
+            break;
+        }
+        if (found && it.t >= best.t) break;
+    }
+}
+
+// Constant-density volume over a shape's event list, RenderableImpl.h:737-777: one free-flight draw per
+// interval of the base shape; a scatter inside the interval is followed by the interval's exit.
+template <class It>
+RT_DEV void walk_volume(const RtDevScene &s, It &it, uint32_t cdv_idx, uint32_t self, float neg_inv_density, float tmin, float tmax,
+                        uint64_t volume_key, const float *scripted, uint32_t n_scripted, bool &found, Best &best) {
+    Pcg vr;
+    vr.state = vr.inc = 0;
+    uint32_t draw = 0, interval = 0;
+    while (csg_next(s, it)) {
+        float t_entry = it.t;
+        uint32_t entry_code = event_code(it);
+        float t2 = RT_INF;
+        uint32_t exit_code = 0;
+        bool has_exit = csg_next(s, it);
+        if (has_exit) { t2 = it.t; exit_code = event_code(it); }
+        float t1 = fmaxf(0.0f, t_entry);
+        if (found && best.t <= t1) return;      // nothing in this or a later interval can beat the current hit
+        if (t1 < t2) {
+            if (!scripted && draw == 0) vr = pcg_seed(volume_key, (uint64_t)(s.cdv_obj[cdv_idx] + 1u));
+            float u = scripted ? scripted[draw % n_scripted] : rnd(vr);
+            draw++;
+            float t = fmaf(logf(1.0f - u), neg_inv_density, t1);
+            if (t <= t2) {
+                uint32_t iv = interval << RT_CODE_INTERVAL_SHIFT;
+                if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = self; best.code = RT_CODE_SCATTER | iv | entry_code; found = true; return; }
+                if (has_exit && in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = self; best.code = iv | exit_code; found = true; return; }
+            }
+        }
+        if (!has_exit) return;
+        interval++;
+    }
+}
 
 // LEAN: the kernel is short of registers (texture code next to the intersection code), so a volume
 // over a primitive goes through the general event walk instead of its own few lines.
 // UNI: `ref` is the same in every lane (the list traversal), so the object's records are read once per wave.
-template <bool SIMPLE, bool MOTION = false, bool LEAN = false, bool UNI = false>
+// WIDE: the scene holds a CSG shape of more than RT_CSG_LEAVES leaves; only kernels built for such scenes carry that walk.
+template <bool SIMPLE, bool MOTION = false, bool LEAN = false, bool UNI = false, bool WIDE = false>
 RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmin, float tmax, uint64_t volume_key,
                         const float *scripted, uint32_t n_scripted, bool &found, Best &best, float time = 0.0f) {
     uint32_t kind = (ref >> RT_KIND_SHIFT) & 7u, idx = ref & RT_INDEX_MASK;
@@ -594,6 +742,13 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
             return;
         }
     }
+    if (WIDE && is_wide_csg(s, shape)) {
+        WideIter w;
+        csg_begin_wide(s, shape, o, d, w);
+        if (volume) walk_volume(s, w, idx, self, neg_inv_density, tmin, tmax, volume_key, scripted, n_scripted, found, best);
+        else walk_boundary(s, w, self, tmin, tmax, found, best);
+        return;
+    }
     CsgIter it;
     csg_begin<UNI>(s, shape, o, d, it);
     if (!volume) {
@@ -606,15 +761,7 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
             }
             return;
         }
-        while (csg_next(s, it)) {
-            if (in_range(it.t, tmin, tmax, found, best.t)) {
-                best.t = it.t; best.ref = self;
-                best.code = event_code(it);
-                found = true;
-                break;
-            }
-            if (found && it.t >= best.t) break;
-        }
+        walk_boundary(s, it, self, tmin, tmax, found, best);
         return;
     }
     // Constant-density volume, RenderableImpl.h:737-777: one free-flight draw per interval of
@@ -626,32 +773,7 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
                                    tmin, tmax, volume_key, scripted, found, best);
         return;
     }
-    Pcg vr;
-    vr.state = vr.inc = 0;
-    uint32_t draw = 0, interval = 0;
-    while (csg_next(s, it)) {
-        float t_entry = it.t;
-        uint32_t entry_code = event_code(it);
-        float t2 = RT_INF;
-        uint32_t exit_code = 0;
-        bool has_exit = csg_next(s, it);
-        if (has_exit) { t2 = it.t; exit_code = event_code(it); }
-        float t1 = fmaxf(0.0f, t_entry);
-        if (found && best.t <= t1) return;      // nothing in this or a later interval can beat the current hit
-        if (t1 < t2) {
-            if (!scripted && draw == 0) vr = pcg_seed(volume_key, (uint64_t)(s.cdv_obj[idx] + 1u));
-            float u = scripted ? scripted[draw % n_scripted] : rnd(vr);
-            draw++;
-            float t = fmaf(logf(1.0f - u), neg_inv_density, t1);
-            if (t <= t2) {
-                uint32_t iv = interval << RT_CODE_INTERVAL_SHIFT;
-                if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = self; best.code = RT_CODE_SCATTER | iv | entry_code; found = true; return; }
-                if (has_exit && in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = self; best.code = iv | exit_code; found = true; return; }
-            }
-        }
-        if (!has_exit) return;
-        interval++;
-    }
+    walk_volume(s, it, idx, self, neg_inv_density, tmin, tmax, volume_key, scripted, n_scripted, found, best);
 }
 
 // ------------------------------------------------------------------ BVH traversal (extend)
@@ -799,7 +921,7 @@ RT_DEV void trav_node16(const uint4 *nodes16, Trav &t, float tmin, uint32_t *sta
 }
 
 // Runs one ray to completion (parity kernels and the wavefront extend stage).
-template <bool SIMPLE, bool MOTION = false>
+template <bool SIMPLE, bool MOTION = false, bool WIDE = false>
 RT_DEV bool trace(const RtDevScene &s, f3 o, f3 d, float tmin, float tmax, uint64_t volume_key,
                   const float *scripted, uint32_t n_scripted, uint32_t *stack, Best &best, float time = 0.0f) {
     Trav t;
@@ -808,7 +930,7 @@ RT_DEV bool trace(const RtDevScene &s, f3 o, f3 d, float tmin, float tmax, uint6
     while (t.cur != RT_REF_NONE) {
         while (!(t.cur & RT_REF_LEAF)) trav_node(nodes, t, tmin, stack);
         if (t.cur != RT_REF_NONE) {
-            test_object<SIMPLE, MOTION>(s, t.cur & ~RT_REF_LEAF, o, d, tmin, tmax, volume_key, scripted, n_scripted, t.found, t.best, time);
+            test_object<SIMPLE, MOTION, false, false, WIDE>(s, t.cur & ~RT_REF_LEAF, o, d, tmin, tmax, volume_key, scripted, n_scripted, t.found, t.best, time);
             trav_pop(t, stack);
         }
     }
@@ -826,16 +948,16 @@ struct HitRecord {
 };
 
 RT_DEV Surface csg_surface(const RtDevScene &s, uint32_t csg_idx, uint32_t code, f3 o, f3 d, float t, bool want_uv) {
-    const RtDevCsg &c = s.csg[csg_idx];
-    uint32_t leaf = (code >> 3) & 7u;
-    Surface sf = prim_surface(s, c.leaf[leaf], code & 7u, o, d, t, want_uv);
-    if ((c.flip_mask >> leaf) & 1u) sf.normal = -sf.normal;      // RenderableImpl.h:712
+    bool flip;
+    const uint32_t leaf_ref = csg_leaf(s, csg_idx, code_leaf<true>(code), flip);
+    Surface sf = prim_surface(s, leaf_ref, code & 7u, o, d, t, want_uv);
+    if (flip) sf.normal = -sf.normal;      // RenderableImpl.h:712
     return sf;
 }
 
 // Surface attributes of the closest hit.  Whatever the object's kind, the hit lies on one leaf
 // primitive (named by best.code for CSG shapes), so the attribute code is reached from one place.
-template <bool MOTION = false>
+template <bool MOTION = false, bool WIDE = true>
 RT_DEV void complete_hit(const RtDevScene &s, Best best, f3 o, f3 d, bool want_uv, HitRecord &h, float time = 0.0f) {
     uint32_t kind = (best.ref >> RT_KIND_SHIFT) & 7u, idx = best.ref & RT_INDEX_MASK;
     h.point = madd(d, best.t, o);
@@ -863,10 +985,7 @@ RT_DEV void complete_hit(const RtDevScene &s, Best best, f3 o, f3 d, bool want_u
     uint32_t leaf_ref = shape;
     bool flip = false;
     if (skind == RT_KIND_CSG) {
-        const RtDevCsg &c = s.csg[sidx];
-        const uint32_t leaf = (best.code >> 3) & 7u;
-        leaf_ref = c.leaf[leaf];
-        flip = (c.flip_mask >> leaf) & 1u;                         // RenderableImpl.h:712
+        leaf_ref = csg_leaf<WIDE>(s, sidx, code_leaf<WIDE>(best.code), flip);
         if (kind == RT_KIND_CSG && !moved) object = s.csg_obj[sidx];
     } else if (kind != RT_KIND_CDV && !moved) {
         object = skind == RT_KIND_SPHERE ? s.sphere_obj[sidx] : s.xprim_obj[sidx];
@@ -876,7 +995,7 @@ RT_DEV void complete_hit(const RtDevScene &s, Best best, f3 o, f3 d, bool want_u
         // RenderableImpl.h:760-766: point on the ray, normal against the ray, material and texture
         // coordinates of the ENTRY hit of the interval, which lies on leaf_ref at its entry or exit
         Span sp = prim_span(s, leaf_ref, o, d);
-        t_surface = ((best.code >> 6) & 1u) ? sp.t1 : sp.t0;
+        t_surface = ((best.code >> RT_CODE_LEAF_EXIT_SHIFT) & 1u) ? sp.t1 : sp.t0;
     }
     Surface sf = prim_surface(s, leaf_ref, best.code & 7u, o, d, t_surface, want_uv || scatter);
     if (flip) sf.normal = -sf.normal;

@@ -294,6 +294,19 @@ void collect_leaves(const RtScene &sc, int id, bool flipped, std::vector<int> &l
     }
 }
 
+// The expression of a CSG shape as a postfix program over its leaves (numbered depth first, like
+// collect_leaves): a node of k operands is k - 1 binary operations folded from the left, which for a
+// subtraction is "the first operand and none of the others".
+void csg_tokens(const RtScene &sc, int id, int &next_leaf, std::vector<uint32_t> &out) {
+    const HostShape &s = sc.shapes[id];
+    if (s.kind != RT_KIND_CSG) { out.push_back((uint32_t)next_leaf++); return; }
+    const uint32_t op = s.op == RT_CSG_UNION ? RT_CSG_TOKEN_UNION : (s.op == RT_CSG_INTERSECTION ? RT_CSG_TOKEN_INTERSECTION : RT_CSG_TOKEN_SUBTRACT);
+    for (size_t i = 0; i < s.children.size(); i++) {
+        csg_tokens(sc, s.children[i], next_leaf, out);
+        if (i > 0) out.push_back(op);
+    }
+}
+
 // inside(shape) for a given leaf-membership mask: the depth counting of
 // Impl/RenderableImpl.h:678-691 in closed form (union: any child; intersection: all
 // children; subtract: first child and none of the others).
@@ -898,6 +911,8 @@ int rt_scene_commit(RtScene *sc) {
     std::vector<float> spheres, sphere_rot, xprims;
     std::vector<uint32_t> sphere_mat, sphere_obj, xprim_mat, xprim_obj, csg_obj, cdv_obj;
     std::vector<RtDevCsg> csg;
+    std::vector<uint32_t> csg_pool;
+    uint32_t n_wide_csg = 0;
     std::vector<RtDevCdv> cdv;
     bool any_rot = false;
     auto owner_object = [&](int id) {
@@ -942,13 +957,30 @@ int rt_scene_commit(RtScene *sc) {
         RtDevCsg rec;
         memset(&rec, 0, sizeof(rec));
         rec.n_leaves = (uint32_t)leaves.size();
-        for (size_t i = 0; i < leaves.size(); i++) {
-            rec.leaf[i] = sc->shapes[leaves[i]].ref;
-            if (flips[i]) rec.flip_mask |= 1u << i;
-        }
-        for (uint32_t mask = 0; mask < (1u << leaves.size()); mask++) {
+        if (leaves.size() > RT_CSG_LEAVES) {
+            // a wide shape: leaves and the expression as a postfix program go to the pool
+            uint64_t flip_mask = 0;
+            for (size_t i = 0; i < leaves.size(); i++)
+                if (flips[i]) flip_mask |= 1ull << i;
+            std::vector<uint32_t> tokens;
             int next = 0;
-            if (eval_csg(*sc, (int)id, mask, next)) rec.truth[mask >> 5] |= 1u << (mask & 31u);
+            csg_tokens(*sc, (int)id, next, tokens);
+            rec.leaf[0] = (uint32_t)csg_pool.size();
+            csg_pool.push_back((uint32_t)flip_mask);
+            csg_pool.push_back((uint32_t)(flip_mask >> 32));
+            csg_pool.push_back((uint32_t)tokens.size());
+            for (int leaf : leaves) csg_pool.push_back(sc->shapes[leaf].ref);
+            csg_pool.insert(csg_pool.end(), tokens.begin(), tokens.end());
+            n_wide_csg++;
+        } else {
+            for (size_t i = 0; i < leaves.size(); i++) {
+                rec.leaf[i] = sc->shapes[leaves[i]].ref;
+                if (flips[i]) rec.flip_mask |= 1u << i;
+            }
+            for (uint32_t mask = 0; mask < (1u << leaves.size()); mask++) {
+                int next = 0;
+                if (eval_csg(*sc, (int)id, mask, next)) rec.truth[mask >> 5] |= 1u << (mask & 31u);
+            }
         }
         s.ref = rt_make_ref(RT_KIND_CSG, (uint32_t)csg.size());
         csg.push_back(rec);
@@ -1100,6 +1132,9 @@ int rt_scene_commit(RtScene *sc) {
     if ((rc = upload(sc, xprim_obj, &d.xprim_obj)) < 0) return rc;
     if ((rc = upload(sc, csg, &d.csg)) < 0) return rc;
     if ((rc = upload(sc, csg_obj, &d.csg_obj)) < 0) return rc;
+    if ((rc = upload(sc, csg_pool, &d.csg_pool)) < 0) return rc;
+    d.n_wide_csg = n_wide_csg;
+    if (n_wide_csg) feat |= RT_FEAT_WIDE_CSG;
     if ((rc = upload(sc, cdv, &d.cdv)) < 0) return rc;
     if ((rc = upload(sc, cdv_obj, &d.cdv_obj)) < 0) return rc;
     if ((rc = upload(sc, motion, &d.motion)) < 0) return rc;

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_first_hit(RtDevScene s, const floa
     f3 o = mk3(r[0], r[1], r[2]), d = mk3(r[3], r[4], r[5]);
     Best b;
     constexpr bool MOTION = (FEAT & RT_FEAT_MOTION) != 0;
-    bool found = trace<!(FEAT & RT_FEAT_XPRIM), MOTION>(s, o, d, tmin, tmax, volume_key, nullptr, 0, stack + threadIdx.x, b, time);
+    bool found = trace<!(FEAT & RT_FEAT_XPRIM), MOTION, (FEAT & RT_FEAT_WIDE_CSG) != 0>(s, o, d, tmin, tmax, volume_key, nullptr, 0, stack + threadIdx.x, b, time);
     RtHit h;
     h.t = 0.f;
     h.point[0] = h.point[1] = h.point[2] = 0.f;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_first_hit(RtDevScene s, const floa
     h.front_face = 0;
     if (found) {
         HitRecord hr;
-        complete_hit<MOTION>(s, b, o, d, true, hr, time);
+        complete_hit<MOTION, (FEAT & RT_FEAT_WIDE_CSG) != 0>(s, b, o, d, true, hr, time);
         h.t = b.t;
         h.point[0] = hr.point.x; h.point[1] = hr.point.y; h.point[2] = hr.point.z;
         h.normal[0] = hr.normal.x; h.normal[1] = hr.normal.y; h.normal[2] = hr.normal.z;
@@ -88,6 +88,73 @@ RT_DEV void put_event(RtEvent *ev, int32_t &n, float t, bool is_exit, const Surf
         e.material_offset = sf->material;
     }
     ev[n++] = e;
+}
+
+// Surface of a shape's boundary event: `code` names the face and, for a CSG shape, the leaf.
+RT_DEV Surface shape_surface(const RtDevScene &s, uint32_t shape, uint32_t code, f3 o, f3 d, float t, bool want_uv) {
+    if (((shape >> RT_KIND_SHIFT) & 7u) == RT_KIND_CSG) return csg_surface(s, shape & RT_INDEX_MASK, code, o, d, t, want_uv);
+    return prim_surface(s, shape, code & 7u, o, d, t, want_uv);
+}
+
+// A primitive's interval as an event list of two (the protocol of the CSG walks).
+struct PrimIter {
+    Span sp;
+    int stage;               // 0: entry next, 1: exit next, 2: done
+    float t;
+    uint32_t leaf, tag;
+    bool is_exit, leaf_exit;
+};
+RT_DEV bool csg_next(const RtDevScene &, PrimIter &it) {
+    if (it.stage > 1) return false;
+    it.is_exit = it.leaf_exit = it.stage == 1;
+    it.t = it.is_exit ? it.sp.t1 : it.sp.t0;
+    it.tag = it.is_exit ? it.sp.tag1 : it.sp.tag0;
+    it.leaf = 0;
+    it.stage++;
+    return true;
+}
+
+template <class It>
+RT_DEV void emit_shape_events(const RtDevScene &s, It &it, uint32_t shape, f3 o, f3 d, RtEvent *ev, int32_t &cnt, f3 wo, f3 wd,
+                              const MotionFrame *fr) {
+    while (csg_next(s, it)) {
+        uint32_t code = event_code(it) & ~(1u << RT_CODE_LEAF_EXIT_SHIFT);
+        Surface sf;
+        if (finite(it.t)) sf = shape_surface(s, shape, code, o, d, it.t, true);
+        put_event(ev, cnt, it.t, it.is_exit, &sf, wo, wd, fr);
+    }
+}
+
+template <class It>
+RT_DEV void emit_volume_events(const RtDevScene &s, It &it, const RtDevCdv &cv, f3 o, f3 d, const float *scripted, int n_scripted,
+                               uint64_t volume_key, uint32_t object, RtEvent *ev, int32_t &cnt) {
+    Pcg vr = pcg_seed(volume_key, (uint64_t)(object + 1u));
+    uint32_t draw = 0;
+    while (csg_next(s, it)) {
+        const float t_entry = it.t;
+        const uint32_t entry_code = event_code(it) & ~(1u << RT_CODE_LEAF_EXIT_SHIFT);
+        float t_exit = RT_INF;
+        uint32_t exit_code = 0;
+        const bool has_exit = csg_next(s, it);
+        if (has_exit) { t_exit = it.t; exit_code = event_code(it) & ~(1u << RT_CODE_LEAF_EXIT_SHIFT); }
+        float t1 = fmaxf(0.f, t_entry);
+        if (t1 < t_exit) {
+            float u = scripted ? scripted[draw % (uint32_t)n_scripted] : rnd(vr);
+            draw++;
+            float t = fmaf(logf(1.f - u), cv.neg_inv_density, t1);
+            if (t <= t_exit) {
+                Surface en = shape_surface(s, cv.base, entry_code, o, d, t_entry, true);
+                en.normal = -d;
+                put_event(ev, cnt, t, false, &en, o, d);
+                if (has_exit) {
+                    Surface ex;
+                    if (finite(t_exit)) ex = shape_surface(s, cv.base, exit_code, o, d, t_exit, true);
+                    put_event(ev, cnt, t_exit, true, &ex, o, d);
+                }
+            }
+        }
+        if (!has_exit) break;
+    }
 }
 
 // All boundary crossings of one shape, in order: the enumerator protocol of
@@ -124,60 +191,31 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intervals(RtDevScene s, uint32_t r
             put_event(ev, cnt, sp.t1, true, &b, wo, wd, fr);
         }
     } else if (kind == RT_KIND_CSG) {
-        CsgIter it;
-        csg_begin(s, ref, o, d, it);
-        while (csg_next(s, it)) {
-            uint32_t code = it.tag | (it.leaf << 3);
-            Surface sf;
-            if (finite(it.t)) sf = csg_surface(s, idx, code, o, d, it.t, true);
-            put_event(ev, cnt, it.t, it.is_exit, &sf, wo, wd, fr);
+        if (is_wide_csg(s, ref)) {
+            WideIter w;
+            csg_begin_wide(s, ref, o, d, w);
+            emit_shape_events(s, w, ref, o, d, ev, cnt, wo, wd, fr);
+        } else {
+            CsgIter it;
+            csg_begin(s, ref, o, d, it);
+            emit_shape_events(s, it, ref, o, d, ev, cnt, wo, wd, fr);
         }
     } else {
         // ConstantDensityVolume<Impl>::HitEnumerator, RenderableImpl.h:727-802
         const RtDevCdv cv = s.cdv[idx];
-        Pcg vr = pcg_seed(volume_key, (uint64_t)(object + 1u));
-        uint32_t draw = 0;
-        uint32_t bkind = (cv.base >> RT_KIND_SHIFT) & 7u, bidx = cv.base & RT_INDEX_MASK;
-        CsgIter it;
-        Span sp = empty_span();
-        bool prim_pending = false;
-        if (bkind == RT_KIND_CSG) csg_begin(s, cv.base, o, d, it);
-        else { sp = prim_span(s, cv.base, o, d); prim_pending = span_valid(sp); }
-        while (true) {
-            float t_entry, t_exit = RT_INF;
-            uint32_t entry_code, exit_code = 0;
-            bool has_exit;
-            if (bkind == RT_KIND_CSG) {
-                if (!csg_next(s, it)) break;
-                t_entry = it.t; entry_code = it.tag | (it.leaf << 3);
-                has_exit = csg_next(s, it);
-                if (has_exit) { t_exit = it.t; exit_code = it.tag | (it.leaf << 3); }
-            } else {
-                if (!prim_pending) break;
-                prim_pending = false;
-                t_entry = sp.t0; entry_code = sp.tag0;
-                has_exit = true; t_exit = sp.t1; exit_code = sp.tag1;
-            }
-            float t1 = fmaxf(0.f, t_entry);
-            if (t1 < t_exit) {
-                float u = scripted ? scripted[draw % (uint32_t)n_scripted] : rnd(vr);
-                draw++;
-                float t = fmaf(logf(1.f - u), cv.neg_inv_density, t1);
-                if (t <= t_exit) {
-                    Surface en = bkind == RT_KIND_CSG ? csg_surface(s, bidx, entry_code, o, d, t_entry, true)
-                                                      : prim_surface(s, cv.base, entry_code, o, d, t_entry, true);
-                    en.normal = -d;
-                    put_event(ev, cnt, t, false, &en, o, d);
-                    if (has_exit) {
-                        Surface ex;
-                        if (finite(t_exit))
-                            ex = bkind == RT_KIND_CSG ? csg_surface(s, bidx, exit_code, o, d, t_exit, true)
-                                                      : prim_surface(s, cv.base, exit_code, o, d, t_exit, true);
-                        put_event(ev, cnt, t_exit, true, &ex, o, d);
-                    }
-                }
-            }
-            if (!has_exit) break;
+        if (((cv.base >> RT_KIND_SHIFT) & 7u) != RT_KIND_CSG) {
+            PrimIter p;
+            p.sp = prim_span(s, cv.base, o, d);
+            p.stage = span_valid(p.sp) ? 0 : 2;
+            emit_volume_events(s, p, cv, o, d, scripted, n_scripted, volume_key, object, ev, cnt);
+        } else if (is_wide_csg(s, cv.base)) {
+            WideIter w;
+            csg_begin_wide(s, cv.base, o, d, w);
+            emit_volume_events(s, w, cv, o, d, scripted, n_scripted, volume_key, object, ev, cnt);
+        } else {
+            CsgIter it;
+            csg_begin(s, cv.base, o, d, it);
+            emit_volume_events(s, it, cv, o, d, scripted, n_scripted, volume_key, object, ev, cnt);
         }
     }
     counts[i] = cnt;
@@ -331,7 +369,7 @@ RT_DEV bool shade_path(const RtDevScene &s, uint32_t background, uint32_t max_de
             h.u = sf.u; h.v = sf.v;
         }
     } else {
-        complete_hit<(FEAT & RT_FEAT_MOTION) != 0>(s, b, o, d, maybe_uv, h, time);
+        complete_hit<(FEAT & RT_FEAT_MOTION) != 0, (FEAT & RT_FEAT_WIDE_CSG) != 0>(s, b, o, d, maybe_uv, h, time);
         m = load_material(s, h.material);
     }
     f3 emitted, atten, nd;
@@ -413,7 +451,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_extend(RtDevScene s, WfQueues q
         Best b;
         float time = 0.f;
         if (FEAT & RT_FEAT_MOTION) time = q.thr[cur][i].w;
-        bool found = trace<!(FEAT & RT_FEAT_XPRIM), (FEAT & RT_FEAT_MOTION) != 0>(s, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), RT_T_MIN,
+        bool found = trace<!(FEAT & RT_FEAT_XPRIM), (FEAT & RT_FEAT_MOTION) != 0, (FEAT & RT_FEAT_WIDE_CSG) != 0>(s, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), RT_T_MIN,
                                                                                 RT_INF, key, nullptr, 0, stack + threadIdx.x, b, time);
         q.hit[i] = make_float4(b.t, __uint_as_float(found ? b.ref : RT_REF_NONE), __uint_as_float(b.code), 0.f);
     }
@@ -647,7 +685,8 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
                     if (x < rc.width && y < rc.height) {
                         g = sample_stream(seed, rc.first_sample + s_begin + (k >> 6), x, y);
                         camera_ray(cam_now, x, y, g, o, d);
-                        if (FEAT & RT_FEAT_MOTION) time = rnd(g);
+                        // the all-features kernel serves still scenes too: it asks the render record
+                        if ((FEAT & RT_FEAT_MOTION) && (!(FEAT & RT_FEAT_WIDE_CSG) || rc.animated)) time = rnd(g);
                         thr = mk3(1, 1, 1);
                         rad = mk3(0, 0, 0);
                         depth = 0;
@@ -748,7 +787,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
                 }
             }
             if (at_leaf) {
-                test_object<SIMPLE, (FEAT & RT_FEAT_MOTION) != 0, (FEAT & RT_FEAT_TEXTURE) != 0>(s, t.cur & ~RT_REF_LEAF, t.o, t.d, RT_T_MIN, RT_INF, key, nullptr, 0, t.found, t.best, time);
+                test_object<SIMPLE, (FEAT & RT_FEAT_MOTION) != 0, (FEAT & RT_FEAT_TEXTURE) != 0, false, (FEAT & RT_FEAT_WIDE_CSG) != 0>(s, t.cur & ~RT_REF_LEAF, t.o, t.d, RT_T_MIN, RT_INF, key, nullptr, 0, t.found, t.best, time);
                 trav_pop<LDS_ENTRIES>(t, stack, deep);
             }
             RT_PROF_END(3, at_leaf);
@@ -798,7 +837,9 @@ static inline int blocks_for(size_t n) { return (int)((n + RT_BLOCK - 1) / RT_BL
 hipError_t rt_launch_first_hit(const RtDevScene &s, uint32_t feat, const float *rays, int n, float tmin, float tmax,
                                uint64_t volume_key, float time, RtHit *out, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    if (feat & RT_FEAT_MOTION)
+    if (feat & RT_FEAT_WIDE_CSG)
+        k_first_hit<15><<<blocks_for(n), RT_BLOCK, 0, stream>>>(s, rays, n, tmin, tmax, volume_key, time, out);
+    else if (feat & RT_FEAT_MOTION)
         k_first_hit<7><<<blocks_for(n), RT_BLOCK, 0, stream>>>(s, rays, n, tmin, tmax, volume_key, time, out);
     else if (feat & RT_FEAT_XPRIM)
         k_first_hit<3><<<blocks_for(n), RT_BLOCK, 0, stream>>>(s, rays, n, tmin, tmax, volume_key, time, out);
@@ -913,7 +954,8 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
         int grid = std::min(blocks_for((size_t)npix * batch), cus * 8);
         grid = (grid + (int)RT_WF_SHARDS - 1) / (int)RT_WF_SHARDS * (int)RT_WF_SHARDS;
         hipError_t e;
-        switch (feat & 7u) {
+        switch ((feat & RT_FEAT_WIDE_CSG) ? 15u : (feat & 7u)) {
+        case 15: e = wavefront_batch<15>(s, cam, r, batch, q, accum, stream, timer, grid); break;
         case 0: e = wavefront_batch<0>(s, cam, r, batch, q, accum, stream, timer, grid); break;
         case 1: e = wavefront_batch<1>(s, cam, r, batch, q, accum, stream, timer, grid); break;
         case 2: e = wavefront_batch<2>(s, cam, r, batch, q, accum, stream, timer, grid); break;
@@ -987,6 +1029,8 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
     const bool n16 = (knobs & 0x20000u) != 0 && s.nodes16 != nullptr;
 #define RT_FUSED(F, ST, W) (n16 ? fused_launch<F, ST, W, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only) \
                                 : fused_launch<F, ST, W, false>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only))
+    // a scene with a wide CSG shape (rare) has one kernel: every feature, the tree
+    if (feat & RT_FEAT_WIDE_CSG) return RT_FUSED(15, RT_STACK_DEPTH, 4);
     if (s.object_list && s.n_listed && !(knobs2 & 0x100u)) {
         // a handful of objects: the list, not the tree (one stack entry is declared and never used).  Untextured
         // scenes run 5 waves per SIMD: 96 registers and 20 spilled ones beat 107 registers at 4 waves by 5 % (6 waves: -1 %);

@@ -15,6 +15,7 @@ enum : uint32_t {
     RT_FEAT_XPRIM = 1u,      // anything other than plain spheres and moving plain spheres in the BVH
     RT_FEAT_TEXTURE = 2u,    // image or Perlin materials
     RT_FEAT_MOTION = 4u,     // moving objects: every sample draws a time
+    RT_FEAT_WIDE_CSG = 8u,   // a CSG shape of more than RT_CSG_LEAVES leaves: one kernel with every feature (15)
 };
 
 // HIP events around every launch of the render loop's dominant kernel, on the stream the

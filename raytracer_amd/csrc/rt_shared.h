@@ -41,16 +41,25 @@ enum RtPrimKind : uint32_t {
 #define RT_STACK_DEPTH 24
 #define RT_BLOCK 256             // threads per workgroup of every traversal kernel
 #define RT_LINEAR_MAX 16         // scenes up to this many objects are rendered without a tree
-#define RT_CSG_LEAVES 8
+#define RT_CSG_LEAVES 8           // leaves whose intervals the walk over a CSG shape keeps in registers
+#define RT_CSG_WIDE_LEAVES 64     // leaves of a shape that is walked by recomputing intervals (RT_CSG_MAX_LEAVES of the C ABI)
+// Postfix program of a wide shape: a token below 64 pushes "inside leaf <token>", the others combine the two on top.
+#define RT_CSG_TOKEN_UNION 64u
+#define RT_CSG_TOKEN_INTERSECTION 65u
+#define RT_CSG_TOKEN_SUBTRACT 66u
 
 static inline uint32_t rt_make_ref(uint32_t kind, uint32_t index) { return (kind << RT_KIND_SHIFT) | index; }
 
+// Up to RT_CSG_LEAVES leaves: the record holds the leaves and the truth table.  More (a "wide" shape): leaf[0] is
+// the shape's offset in RtDevScene::csg_pool, where flip mask (2 words), token count, the leaf references and the
+// postfix program of the expression follow one another; flip_mask and truth are unused.
 struct RtDevCsg {
     uint32_t n_leaves;
     uint32_t flip_mask;                 // bit i: leaf i sits under an odd number of subtract right-hand sides
     uint32_t leaf[RT_CSG_LEAVES];       // primitive references (kind | index), depth-first order
     uint32_t truth[8];                  // inside(root) for every leaf-membership mask (256 bits)
 };
+#define RT_CSG_POOL_HEADER 3u
 
 struct RtDevCdv {
     uint32_t base;                      // primitive or CSG reference
@@ -111,6 +120,7 @@ struct RtDevScene {
     const uint32_t *xprim_obj;
     const RtDevCsg *csg;
     const uint32_t *csg_obj;
+    const uint32_t *csg_pool;      // leaves and postfix programs of the wide CSG shapes
     const RtDevCdv *cdv;
     const uint32_t *cdv_obj;
     const RtDevMotion *motion;
@@ -126,7 +136,7 @@ struct RtDevScene {
     // tests every object in turn, the same object in all lanes at once, instead of walking a tree.
     const uint32_t *object_list;
     uint32_t n_listed;             // 0 when there is no list
-    uint32_t pad0;
+    uint32_t n_wide_csg;           // CSG shapes with more than RT_CSG_LEAVES leaves (0: the kernels skip the check)
     uint32_t root;                 // child reference of the root (RT_REF_NONE for an empty scene)
     uint32_t n_nodes;
     uint32_t kit_convention;       // 1: RayTracingKit's texture coordinates and metal rule (RT_CONVENTION_KIT)

@@ -196,15 +196,18 @@ def test_description_limits_and_errors_without_a_gpu():
     sph.material_offset = 0
     ids = [lib.rt_shape_sphere(h, C.byref(sph)) for _ in range(10)]
     assert ids == list(range(10))
-    arr9 = (C.c_int * 9)(*ids[:9])
-    assert lib.rt_shape_csg(h, abi.RT_CSG_UNION, 9, arr9) == -3            # RT_ERR_LIMIT: more than 8 leaves
+    many = [lib.rt_shape_sphere(h, C.byref(sph)) for _ in range(65)]
+    arr65 = (C.c_int * 65)(*many)
+    assert lib.rt_shape_csg(h, abi.RT_CSG_UNION, 65, arr65) == -3          # RT_ERR_LIMIT: more than 64 leaves
+    arr9 = (C.c_int * 9)(*many[:9])
+    assert lib.rt_shape_csg(h, abi.RT_CSG_UNION, 9, arr9) == 75            # more than 8 leaves: a wide shape
     arr8 = (C.c_int * 8)(*ids[:8])
     u = lib.rt_shape_csg(h, abi.RT_CSG_UNION, 8, arr8)
-    assert u == 10
+    assert u == 76
     assert lib.rt_shape_csg(h, abi.RT_CSG_UNION, 8, arr8) < 0              # children already in use
     assert lib.rt_add_object(h, ids[0]) < 0                                # a CSG child is not an object
     fog = lib.rt_shape_cdv(h, ids[8], 0.5)
-    assert fog == 11
+    assert fog == 77
     assert lib.rt_shape_cdv(h, fog, 0.5) < 0                               # volume of a volume
     two = (C.c_int * 2)(ids[9], fog)
     assert lib.rt_shape_csg(h, abi.RT_CSG_SUBTRACT, 2, two) < 0            # volume as a CSG operand

@@ -264,6 +264,85 @@ def test_every_csg_operator_and_volume_over_csg(ctx):
     assert bad <= 3
 
 
+def wide_shapes():
+    """CSG shapes of more than eight leaf primitives (RayTracingKit/CSG.swift:37-119 puts no bound on
+    nesting): the HIP path walks them by recomputing leaf intervals and evaluating the expression."""
+    mats = [ColoredLambertian((0.05 * i, 0.5, 0.5)) for i in range(1, 21)]
+    cyl = lambda tr, k: Cylinder(tr, 0.45, 4, bottom=mats[k], top=mats[k + 1], side=mats[k + 2])
+    row = [Sphere((0.6 * i - 3.3, 0, 0), 0.5, mats[i]) for i in range(12)]
+    chain = Sphere((-2.0, 0.3, 0), 0.6, mats[0])
+    for i in range(1, 10):                                   # ten leaves, nested to the right: the deepest expression stack
+        chain = Union(Sphere((-2.0 + 0.45 * i, 0.3 * (-1) ** i, 0), 0.6, mats[i]), chain)
+    drilled = Subtract(
+        Union(Cuboid(T.translate(-2, -1, -1), (4, 2, 2), mats[0]), Sphere((2, 0, 0), 1.2, mats[1]), Sphere((-2, 0, 0), 1.2, mats[2])),
+        Union(Union(cyl(T.translate(0, -2, 0), 3), cyl(T.rotation_deg(90, "x") * T.translate(0, -2, 0), 6)),
+              Intersection(Cuboid(T.translate(0.5, 0.2, -2), (1, 1, 4), mats[9]), Sphere((1, 0.7, 0), 0.8, mats[10])),
+              Subtract(Sphere((-1.2, 0.9, 0.2), 0.7, mats[11]), Sphere((-1.2, 1.2, 0.2), 0.45, mats[12])),
+              cyl(T.rotation_deg(90, "z") * T.translate(0, -2, 0), 13)))          # 3 + (2 + 2 + 2 + 1) = 10 leaves, every operator, a subtraction inside a subtraction
+    return {"twelve_spheres": Union(*row), "ten_nested_right": chain, "drilled_block": drilled}
+
+
+def test_csg_shapes_of_more_than_eight_leaves(ctx):
+    from raytracer_amd.renderer import NativeScene, Renderer, camera_rays
+    from raytracer_amd.scene import ColoredIsotropic, ColoredMetal, Dielectric
+    for name, shape in wide_shapes().items():
+        nat = NativeScene(ctx)
+        sid = shape.as_impl(SceneEncoder(nat))
+        nat.commit()
+        orc = ob.OracleScene()
+        oid = shape.as_impl(SceneEncoder(orc))
+        rays = random_rays(1500, 23, radius=7.0, aim_radius=2.0)
+        bad = _interval_mismatches(nat, sid, orc, oid, rays)
+        print(name, "mismatches", bad)
+        assert bad <= 3, name
+    # a volume over a wide shape, scripted draws
+    iso = ColoredIsotropic((1, 1, 1))
+    lumps = [Sphere((0.8 * i - 3.6, 0.2 * (-1) ** i, 0), 0.55, iso) for i in range(10)]
+    fog = ConstantDensityVolume(Subtract(Union(*lumps), Cuboid(T.translate(-0.5, -2, -2), (1, 4, 4), iso)), 0.7)
+    nat = NativeScene(ctx)
+    sid = fog.as_impl(SceneEncoder(nat))
+    nat.commit()
+    orc = ob.OracleScene()
+    oid = fog.as_impl(SceneEncoder(orc))
+    rays = random_rays(1500, 24, radius=7.0, aim_radius=1.5)
+    bad = _interval_mismatches(nat, sid, orc, oid, rays, scripted=[0.3, 0.9, 0.05, 0.6])
+    print("fog over a wide shape, mismatches", bad)
+    assert bad <= 3
+    # in a scene: first hits and a render (the kernel that carries the wide walk) against the oracle
+    shapes = wide_shapes()
+    glass = Dielectric(1.5)
+    beads = Union(*[Sphere((0.5 * i - 2.5, 1.6, 0.5), 0.35, glass) for i in range(11)])
+    scene = Scene(CameraConfig(vertical_fov=45, look_from=(1.5, 3, 8), look_at=(0, 0.3, 0)), [
+        Sphere((0, -101.2, 0), 100.0, ColoredLambertian((0.5, 0.5, 0.5))),
+        shapes["drilled_block"], beads,
+        Sphere((3.2, 0, 1), 0.9, ColoredMetal((0.8, 0.7, 0.5), 0.05)),
+        ConstantDensityVolume(Sphere((-3.4, 0.2, 1.2), 1.0, iso), 0.8),
+    ])
+    nat = NativeScene(ctx)
+    scene.encode(nat)
+    nat.commit()
+    orc = ob.oracle_scene_from(scene)
+    rays = np.concatenate([camera_rays(ctx, scene.camera, RenderConfig(1, 1, 1, 5, 0), 160, 90),
+                           random_rays(4000, 9, center=(0, 0.5, 0), radius=9.0, aim_radius=4.0)]).astype(np.float32)
+    compare_first_hits(nat.first_hit(rays), orc.first_hit(rays), rays, scene, what="wide csg scene")
+    w, h, spp, depth, seed = 128, 72, 16, 12, 11
+    ref, _, _ = orc.render(scene.camera, RenderConfig(spp, depth, 1, seed, 0), w, h, precision=ob.ORC_F64)
+    ref = ref / spp
+    from test_gpu_render import psnr
+    imgs = []
+    for pipeline in (abi.RT_PIPELINE_FUSED, abi.RT_PIPELINE_WAVEFRONT):
+        r = Renderer(scene, w, h, pipeline=pipeline, ctx=ctx)
+        r.draw(spp, depth, seed)
+        torch.cuda.synchronize()
+        img = r.mean().cpu().numpy().astype(np.float64)
+        imgs.append(img)
+        p = psnr(img, ref)
+        same = (np.abs(img - ref) <= 1e-3).mean()
+        print("wide csg scene, pipeline", pipeline, "PSNR %.1f dB, pixels equal to 1e-3: %.3f" % (p, same))
+        assert p >= 90.0 and same > 0.995     # measured on MI355X: 109.1 dB, every pixel equal
+    assert psnr(imgs[0], imgs[1]) >= 60.0
+
+
 def test_sphere_cloud_bulk_entry_point(ctx):
     """100k spheres through rt_add_sphere_objects: stats, BVH depth bound, first hits."""
     from raytracer_amd.renderer import NativeScene, camera_rays
