@@ -20,7 +20,9 @@
 #include "rt_device.h"
 #include "rt_launch.h"
 
+#ifndef RT_WPS0
 #define RT_WPS0 8              // waves per SIMD of the spheres-only kernel (64 VGPRs)
+#endif
 #define RT_WPS_DEEP 7          // ... of its deep-tree form: 72 VGPRs, measured +5 % on the million-sphere workload over 8 (6: +-0)
 #ifndef RT_WPS_MOVING_SPHERES
 #define RT_WPS_MOVING_SPHERES 6   // ... of the spheres-and-moving-spheres kernel
