@@ -283,8 +283,8 @@ RT_DEV Span quad_span(const XPrim &x, f3 o, f3 d, float &alpha, float &beta) {
     alpha = beta = 0.0f;
     if (finite(t)) {
         f3 p = madd(d, t, o) - x.c0;
-        alpha = dot(x.t, cross(p, x.c2));
-        beta = dot(x.t, cross(x.c1, p));
+        alpha = dot(x.c1, p);          // c1 = v x w, c2 = w x u (taken on the host): the triple products of RenderableImpl.h:418-426
+        beta = dot(x.c2, p);
         if (!(alpha < 0.0f || alpha > 1.0f || beta < 0.0f || beta > 1.0f)) {
             sp.t0 = denom < 0.0f ? t : -RT_INF;
             sp.t1 = denom < 0.0f ? RT_INF : t;
@@ -386,8 +386,8 @@ RT_DEV Surface prim_surface(const RtDevScene &s, uint32_t ref, uint32_t tag, f3 
     r.normal = mk3(x.p0, x.p1, x.p2);
     r.material = mats[0];
     f3 q = p - x.c0;
-    r.u = dot(x.t, cross(q, x.c2));
-    r.v = dot(x.t, cross(x.c1, q));
+    r.u = dot(x.c1, q);
+    r.v = dot(x.c2, q);
     return r;
 }
 

@@ -936,7 +936,14 @@ int rt_scene_commit(RtScene *sc) {
             s.ref = rt_make_ref(s.kind, (uint32_t)(xprims.size() / 16));
             float rec[16] = {0};
             if (s.kind == RT_KIND_QUAD) {
+                // The planar coordinates of RenderableImpl.h:418-426, alpha = w . (q x v) and beta = w . (u x q)
+                // for q = hit point - origin, are the triple products q . (v x w) and q . (w x u): the two
+                // cross products are taken here once (in double), the kernels evaluate two dot products.
                 memcpy(rec, s.quad, sizeof(rec));
+                const float *v = s.quad + 6, *u = s.quad + 3, *w = s.quad + 9;
+                const double A[3] = {(double)v[1] * w[2] - (double)v[2] * w[1], (double)v[2] * w[0] - (double)v[0] * w[2], (double)v[0] * w[1] - (double)v[1] * w[0]};
+                const double B[3] = {(double)w[1] * u[2] - (double)w[2] * u[1], (double)w[2] * u[0] - (double)w[0] * u[2], (double)w[0] * u[1] - (double)w[1] * u[0]};
+                for (int a = 0; a < 3; a++) { rec[3 + a] = (float)A[a]; rec[6 + a] = (float)B[a]; rec[9 + a] = 0.f; }
             } else {
                 memcpy(rec, s.rot, 36);
                 memcpy(rec + 9, s.trans, 12);

@@ -11,7 +11,7 @@
 //   spheres    float4 (cx, cy, cz, r) per sphere: the whole geometry of the common case
 //              in one 16-byte load; material ids and UV rotations are separate streams
 //              that only the shade stage touches.
-//   xprims     4 x float4 per cylinder / cuboid / quad (rotation, translation, extents).
+//   xprims     4 x float4 per cylinder / cuboid (rotation, translation, extents) / quad (origin, v x w, w x u, -, normal, d).
 //   prim_mat   per-face material ids of the xprims (6 per record), sphere_mat for spheres.
 //   csg / cdv  small records naming leaf primitives; a CSG tree is flattened to a truth
 //              table over its leaves.
