@@ -274,7 +274,7 @@ RT_DEV Span cuboid_span(const XPrim &x, f3 o, f3 d) {
 }
 
 // Impl/RenderableImpl.h:395-436: the quad as the half space behind its plane, cut to
-// the parallelogram.  Record: origin (c0), u (c1), v (c2), w (t), normal (p0..p2), d (p3).
+// the parallelogram.  Record: origin (c0), v x w (c1), w x u (c2), normal (p0..p2), d (p3).
 RT_DEV Span quad_span(const XPrim &x, f3 o, f3 d, float &alpha, float &beta) {
     f3 normal = mk3(x.p0, x.p1, x.p2);
     float denom = dot(d, normal);

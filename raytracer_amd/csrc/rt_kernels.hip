@@ -24,6 +24,9 @@
 #define RT_WPS0 8              // waves per SIMD of the spheres-only kernel (64 VGPRs)
 #endif
 #define RT_WPS_DEEP 7          // ... of its deep-tree form: 72 VGPRs, measured +5 % on the million-sphere workload over 8 (6: +-0)
+#ifndef RT_WPS_LIST1
+#define RT_WPS_LIST1 5         // ... of the list kernel of untextured scenes
+#endif
 #ifndef RT_WPS_MOVING_SPHERES
 #define RT_WPS_MOVING_SPHERES 6   // ... of the spheres-and-moving-spheres kernel
 #endif
@@ -1035,12 +1038,12 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
     if (feat & RT_FEAT_WIDE_CSG) return RT_FUSED(15, RT_STACK_DEPTH, 4);
     if (s.object_list && s.n_listed && !(knobs2 & 0x100u)) {
         // a handful of objects: the list, not the tree (one stack entry is declared and never used).  Untextured
-        // scenes run 5 waves per SIMD: 96 registers and 20 spilled ones beat 107 registers at 4 waves by 5 % (6 waves: -1 %);
-        // with texture code next to it the same trade loses (-13 % on the Kit's second world)
+        // scenes run 5 waves per SIMD (96 registers; 4 waves: -8 %, 6 waves with 32 spilled registers: +-0);
+        // with texture code next to it 4 waves win (5: -13 % on the Kit's second world)
 #define RT_FUSED_LIST(F, W) fused_launch<F, 1, W, false, false, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only)
         switch (feat & 7u) {
         case 0: return RT_FUSED_LIST(0, RT_WPS0);
-        case 1: return RT_FUSED_LIST(1, 5);
+        case 1: return RT_FUSED_LIST(1, RT_WPS_LIST1);
         case 2: return RT_FUSED_LIST(2, 5);
         case 3: return RT_FUSED_LIST(3, 4);
         case 4: case 5: return RT_FUSED_LIST(5, 4);
