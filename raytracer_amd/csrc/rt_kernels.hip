@@ -146,7 +146,7 @@ RT_DEV void emit_volume_events(const RtDevScene &s, It &it, const RtDevCdv &cv, 
         if (t1 < t_exit) {
             float u = scripted ? scripted[draw % (uint32_t)n_scripted] : rnd(vr);
             draw++;
-            float t = fmaf(logf(1.f - u), cv.neg_inv_density, t1);
+            float t = fmaf(log_unit(1.f - u), cv.neg_inv_density, t1);
             if (t <= t_exit) {
                 Surface en = shape_surface(s, cv.base, entry_code, o, d, t_entry, true);
                 en.normal = -d;
