@@ -25,7 +25,7 @@ scene, w, h, _, depth, seed = scenes.make_workload(name)
 import os as _os
 from raytracer_amd import abi  # noqa: E402
 _nodes = {"auto": abi.RT_NODES_AUTO, "f32": abi.RT_NODES_F32, "f16": abi.RT_NODES_F16}[_os.environ.get("RT_NODES", "auto")]
-r = Renderer(scene, w, h, profile_phases=True, nodes=_nodes)
+r = Renderer(scene, w, h, profile_phases=True, nodes=_nodes, refill=int(_os.environ["RT_REFILL"]) if "RT_REFILL" in _os.environ else None)
 r.draw(spp, depth, seed)
 torch.cuda.synchronize()
 pc = r.workspace[256:256 + 96].cpu().numpy().view(np.uint64).reshape(4, 3)
