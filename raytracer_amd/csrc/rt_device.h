@@ -428,8 +428,10 @@ RT_DEV bool csg_lookup(const RtDevScene &s, const CsgIter &it, uint32_t mask) {
 // Starts the walk over `shape`: a CSG shape, or a primitive taken as a shape of one leaf (inside
 // the shape = inside the leaf).  One loop serves both, so the primitive interval code exists once
 // in a kernel however many kinds of object lead here.
+// only_first: the caller reads nothing but leaf 0's interval (a plain primitive tested for its two boundaries), so
+// the other seven are neither cleared nor written.
 template <bool UNI = false>
-RT_DEV void csg_begin(const RtDevScene &s, uint32_t shape, f3 o, f3 d, CsgIter &it) {
+RT_DEV void csg_begin(const RtDevScene &s, uint32_t shape, f3 o, f3 d, CsgIter &it, bool only_first = false) {
     const bool is_csg = ((shape >> RT_KIND_SHIFT) & 7u) == RT_KIND_CSG;
     const uint32_t idx = shape & RT_INDEX_MASK;
     const RtDevCsg *c = s.csg + (is_csg ? idx : 0u);
@@ -438,15 +440,21 @@ RT_DEV void csg_begin(const RtDevScene &s, uint32_t shape, f3 o, f3 d, CsgIter &
     it.entered = it.exited = 0;
     it.truth0 = is_csg ? ld<UNI>(&c->truth[0]) : 2u;         // one leaf: inside exactly when mask = 1
     it.wide_csg = n > 5u ? idx : RT_REF_NONE;
+    if (!only_first) {
 #pragma unroll
-    for (int i = 0; i < RT_CSG_LEAVES; i++) { it.tin[i] = RT_INF; it.tout[i] = RT_INF; }
+        for (int i = 0; i < RT_CSG_LEAVES; i++) { it.tin[i] = RT_INF; it.tout[i] = RT_INF; }
+    }
     for (uint32_t i = 0; i < n; i++) {
         Span sp = prim_span<UNI>(s, is_csg ? ld<UNI>(&c->leaf[i]) : shape, o, d);
         bool ok = span_valid(sp);
         float a = ok ? sp.t0 : RT_INF, b = ok ? sp.t1 : RT_INF;
+        if (only_first) {
+            it.tin[0] = a; it.tout[0] = b;
+        } else {
 #pragma unroll
-        for (int j = 0; j < RT_CSG_LEAVES; j++) {
-            if (j == (int)i) { it.tin[j] = a; it.tout[j] = b; }
+            for (int j = 0; j < RT_CSG_LEAVES; j++) {
+                if (j == (int)i) { it.tin[j] = a; it.tout[j] = b; }
+            }
         }
         it.tags |= (uint64_t)(sp.tag0 | (sp.tag1 << 3)) << (6u * i);
         if (!ok) { it.entered |= 1u << i; it.exited |= 1u << i; }     // nothing left to visit
@@ -753,7 +761,7 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
         return;
     }
     CsgIter it;
-    csg_begin<UNI>(s, shape, o, d, it);
+    csg_begin<UNI>(s, shape, o, d, it, !volume && kind <= RT_KIND_QUAD);
     if (!volume) {
         if (kind <= RT_KIND_QUAD) {
             // one interval: entry, else exit (Shaders.metal:182-199 on a two-hit enumerator)
