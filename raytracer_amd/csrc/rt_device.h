@@ -314,6 +314,14 @@ struct Surface {
     uint32_t material;
 };
 
+// Material of surface `tag` of primitive `ref` (what prim_surface reports, without the geometry).
+RT_DEV uint32_t prim_material(const RtDevScene &s, uint32_t ref, uint32_t tag) {
+    const uint32_t kind = (ref >> RT_KIND_SHIFT) & 7u, idx = ref & RT_INDEX_MASK;
+    if (kind == RT_KIND_SPHERE) return s.sphere_mat[idx];
+    const uint32_t *mats = s.xprim_mat + 6u * idx;
+    return kind == RT_KIND_QUAD ? mats[0] : mats[tag];        // cylinder: 0 bottom, 1 top, 2 side; cuboid: its six faces
+}
+
 // Attributes of the boundary of primitive `ref` at parameter t on surface `tag`:
 // normals and texture coordinates of RenderableImpl.h:72-86 (sphere), :113-121,141-146,
 // 181-189,203-208 (cylinder), :350-392 (cuboid), :418-426 (quad).
@@ -966,10 +974,33 @@ RT_DEV Surface csg_surface(const RtDevScene &s, uint32_t csg_idx, uint32_t code,
     return sf;
 }
 
+// ------------------------------------------------------------------ materials (shade)
+// Material record: 8 floats = kind, texture id, fuzz, refraction index, albedo rgb, pad.
+struct Material { uint32_t kind, texture; float fuzz, ior; f3 albedo; };
+RT_DEV Material unpack_material(float4 a, float4 b);
+RT_DEV Material load_material(const RtDevScene &s, uint32_t id) {
+    const float4 *q = (const float4 *)s.materials + 2u * id;
+    return unpack_material(q[0], q[1]);
+}
+RT_DEV Material unpack_material(float4 a, float4 b) {
+    Material m;
+    m.kind = __float_as_uint(a.x);
+    m.texture = __float_as_uint(a.y);
+    m.fuzz = a.z;
+    m.ior = a.w;
+    m.albedo = mk3(b.x, b.y, b.z);
+    return m;
+}
+RT_DEV bool material_wants_uv(uint32_t kind) { return kind == 2u || kind == 5u || kind >= 10u; }
+
 // Surface attributes of the closest hit.  Whatever the object's kind, the hit lies on one leaf
 // primitive (named by best.code for CSG shapes), so the attribute code is reached from one place.
+// by_material (with m_out): texture coordinates are worked out only when the hit's material reads them (an image or
+// one of the Kit's textures) - the arc tangent and arc cosine of a sphere or a tube cost as much as the rest of this
+// function - and the material record comes back through m_out.
 template <bool MOTION = false, bool WIDE = true>
-RT_DEV void complete_hit(const RtDevScene &s, Best best, f3 o, f3 d, bool want_uv, HitRecord &h, float time = 0.0f) {
+RT_DEV void complete_hit(const RtDevScene &s, Best best, f3 o, f3 d, bool want_uv, HitRecord &h, float time = 0.0f,
+                         bool by_material = false, Material *m_out = nullptr) {
     uint32_t kind = (best.ref >> RT_KIND_SHIFT) & 7u, idx = best.ref & RT_INDEX_MASK;
     h.point = madd(d, best.t, o);
     const f3 world_d = d;
@@ -1008,6 +1039,10 @@ RT_DEV void complete_hit(const RtDevScene &s, Best best, f3 o, f3 d, bool want_u
         Span sp = prim_span(s, leaf_ref, o, d);
         t_surface = ((best.code >> RT_CODE_LEAF_EXIT_SHIFT) & 1u) ? sp.t1 : sp.t0;
     }
+    if (by_material) {
+        *m_out = load_material(s, prim_material(s, leaf_ref, best.code & 7u));
+        want_uv = want_uv && material_wants_uv(m_out->kind);
+    }
     Surface sf = prim_surface(s, leaf_ref, best.code & 7u, o, d, t_surface, want_uv || scatter);
     if (flip) sf.normal = -sf.normal;
     if (scatter) sf.normal = -d;
@@ -1018,25 +1053,6 @@ RT_DEV void complete_hit(const RtDevScene &s, Best best, f3 o, f3 d, bool want_u
     if (dot(sf.normal, world_d) > 0.0f) { h.normal = -sf.normal; h.front = false; }
     else { h.normal = sf.normal; h.front = true; }
 }
-
-// ------------------------------------------------------------------ materials (shade)
-// Material record: 8 floats = kind, texture id, fuzz, refraction index, albedo rgb, pad.
-struct Material { uint32_t kind, texture; float fuzz, ior; f3 albedo; };
-RT_DEV Material unpack_material(float4 a, float4 b);
-RT_DEV Material load_material(const RtDevScene &s, uint32_t id) {
-    const float4 *q = (const float4 *)s.materials + 2u * id;
-    return unpack_material(q[0], q[1]);
-}
-RT_DEV Material unpack_material(float4 a, float4 b) {
-    Material m;
-    m.kind = __float_as_uint(a.x);
-    m.texture = __float_as_uint(a.y);
-    m.fuzz = a.z;
-    m.ior = a.w;
-    m.albedo = mk3(b.x, b.y, b.z);
-    return m;
-}
-RT_DEV bool material_wants_uv(uint32_t kind) { return kind == 2u || kind == 5u || kind >= 10u; }
 
 // MaterialsImpl.h:53-58: normalised coordinates, nearest texel, clamp to edge; v = 0 is the
 // bottom row (the loader's bottom-left origin), rows are stored top to bottom.

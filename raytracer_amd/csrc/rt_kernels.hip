@@ -374,8 +374,7 @@ RT_DEV bool shade_path(const RtDevScene &s, uint32_t background, uint32_t max_de
             h.u = sf.u; h.v = sf.v;
         }
     } else {
-        complete_hit<(FEAT & RT_FEAT_MOTION) != 0, (FEAT & RT_FEAT_WIDE_CSG) != 0>(s, b, o, d, maybe_uv, h, time);
-        m = load_material(s, h.material);
+        complete_hit<(FEAT & RT_FEAT_MOTION) != 0, (FEAT & RT_FEAT_WIDE_CSG) != 0>(s, b, o, d, maybe_uv, h, time, true, &m);
     }
     f3 emitted, atten, nd;
     bool did = scatter<(FEAT & RT_FEAT_TEXTURE) != 0>(s, m, d, h, g, emitted, atten, nd);
