@@ -24,6 +24,10 @@
 #define RT_WPS0 8              // waves per SIMD of the spheres-only kernel (64 VGPRs)
 #endif
 #define RT_WPS_DEEP 7          // ... of its deep-tree form: 72 VGPRs, measured +5 % on the million-sphere workload over 8 (6: +-0)
+#ifndef RT_WPS_XPRIM
+#define RT_WPS_XPRIM 4         // ... of the tree kernels of scenes with cylinders, boxes, quads, CSG shapes or volumes: 128 VGPRs, no scratch;
+                               // left free the textured one takes 137 registers and runs at 3 waves, 14 % slower on the CSG / textured workload
+#endif
 #ifndef RT_WPS_LIST1
 #define RT_WPS_LIST1 5         // ... of the list kernel of untextured scenes
 #endif
@@ -1061,9 +1065,9 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
             if (!prepare_only) return e;
         }
         return RT_FUSED(0, RT_STACK_DEPTH, 5);
-    case 1: return RT_FUSED(1, RT_STACK_DEPTH, 4);
+    case 1: return RT_FUSED(1, RT_STACK_DEPTH, RT_WPS_XPRIM);
     case 2: return RT_FUSED(2, RT_STACK_DEPTH, 5);
-    case 3: return RT_FUSED(3, RT_STACK_DEPTH, 4);
+    case 3: return RT_FUSED(3, RT_STACK_DEPTH, RT_WPS_XPRIM);
     case 4:
         // spheres and moving spheres only: the spheres kernel with the frame change in front of its sphere test
         if (bvh_depth <= 16) return RT_FUSED(4, 16, RT_WPS_MOVING_SPHERES);
