@@ -547,14 +547,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_accumulate(const float4 *sample
 // registers: only ray generation reads it, and two dozen scalar registers held for the whole
 // kernel made the compiler spill scalars inside the traversal loops.
 #define RT_FUSED_CAMERA_OFFSET 2048u
+#define RT_FUSED_DIAG_OFFSET 1024u   // the diagnostic build's phase counters
+#define RT_ITEM_COUNTERS 8u
+#define RT_ITEM_COUNTER_STRIDE 32u    // words between item counters (128 bytes): the first kilobyte of the workspace
 #define RT_FUSED_DEEP_OFFSET 4096u
 __global__ void k_fused_setup(uint32_t *workspace, RtDevCamera cam) {
-    for (uint32_t i = threadIdx.x; i < RT_FUSED_CAMERA_OFFSET / 4u; i += blockDim.x) workspace[i] = 0u;   // work counter, diagnostics
+    for (uint32_t i = threadIdx.x; i < RT_FUSED_CAMERA_OFFSET / 4u; i += blockDim.x) workspace[i] = 0u;   // item counters, diagnostics
     if (threadIdx.x == 0) *(RtDevCamera *)((char *)workspace + RT_FUSED_CAMERA_OFFSET) = cam;
 }
 
 // PROF = true is a diagnostic build: it counts, per phase, wave-level executions, the lanes
-// that took part, and shader cycles, into 16 words behind the work counter.  Its run time
+// that took part, and shader cycles, into the workspace header (RT_FUSED_DIAG_OFFSET).  Its run time
 // means nothing (the stamps serialise the phases).
 // STACK: LDS stack entries per lane; WPS: waves per SIMD the register allocation is bounded
 // for.  Spheres-only scenes run at 8 waves per SIMD (64 VGPRs, 19 KB of LDS per workgroup: 16
@@ -569,7 +572,7 @@ __global__ void k_fused_setup(uint32_t *workspace, RtDevCamera cam) {
 template <int FEAT, bool PROF, int STACK, int WPS, bool NODE16, bool DEEP = false, bool LIST = false>
 __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtDevCamera *camp, uint32_t background, RtDevRender rc, float *accum,
                                                      uint32_t *counter, uint32_t n_items, uint32_t tiles_x,
-                                                     uint32_t n_tiles, uint32_t chunk_spp, uint32_t knobs, uint32_t heavy_min) {
+                                                     uint32_t n_tiles, uint32_t chunk_spp, uint32_t knobs, uint32_t heavy_and_counters) {
     __shared__ uint32_t stack_mem[STACK * RT_BLOCK];
     constexpr int LDS_ENTRIES = DEEP ? STACK : 0;
     DeepStack deep_cols;
@@ -583,6 +586,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
     // it waits until 16 lanes are free.  Without the disk it is cheap and free lanes are not left idle.
     const uint32_t raygen_min = (knobs >> 18) & 127u;
     const uint32_t leaf_max = (knobs >> 25) & 127u;
+    const uint32_t counters_log2 = heavy_and_counters >> 8, heavy_min = heavy_and_counters & 127u;
     const uint32_t lane = lane_id();
     uint32_t *stack = stack_mem + threadIdx.x;
     float *acc = tile_acc[threadIdx.x >> 6];
@@ -601,7 +605,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
     // (tx0, ty0): the tile's corner in the accumulator; gy0: its first row in the image (they
     // differ when the accumulator holds one shard's bands only)
     uint32_t next = 0, total = 0, tx0 = 0, ty0 = 0, gy0 = 0, s_begin = 0;
-    bool more = true;                  // the item counter has not run out yet
+    bool more = true;                  // this workgroup's item counter has not run out yet
     bool has_path = false, direct = false;
     f3 thr = mk3(0, 0, 0), rad = mk3(0, 0, 0);
     uint32_t depth = 0, pxy = 0;       // accumulator pixel of the lane's path: x | y << 16
@@ -655,9 +659,15 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
                 acc[lane] = 0.f; acc[lane + 64] = 0.f; acc[lane + 128] = 0.f;
             }
             direct = direct || has_path;
+            // Items are dealt by up to RT_ITEM_COUNTERS counters on separate cache lines, counter c dealing items c,
+            // c + n, c + 2n ...: one word takes about 90 returning atomics per microsecond, which a launch of many
+            // small items (a few samples per pixel) would wait on.  A workgroup stays with one counter; eight
+            // neighbouring workgroups (one per XCD under round-robin placement) share it, so every counter is served by
+            // an even sample of the chip and, holding an equal share of interleaved items, they run out together.
+            const uint32_t which_counter = (blockIdx.x >> 3) & ((1u << counters_log2) - 1u);
             uint32_t item = 0;
-            if (lane == 0) item = atomicAdd(counter, 1u);
-            item = __builtin_amdgcn_readfirstlane(item);
+            if (lane == 0) item = atomicAdd(counter + RT_ITEM_COUNTER_STRIDE * which_counter, 1u);
+            item = (__builtin_amdgcn_readfirstlane(item) << counters_log2) | which_counter;
             next = total = 0;
             if (item >= n_items) {
                 more = false;                    // every wave gets here: the grid drains
@@ -804,7 +814,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
         }
     }
     if (PROF && lane == 0) {
-        unsigned long long *out = (unsigned long long *)(counter + 64);
+        unsigned long long *out = (unsigned long long *)(counter + RT_FUSED_DIAG_OFFSET / 4u);
         for (int k = 0; k < 12; k++) atomicAdd(out + k, pc[k]);
     }
 #undef RT_PROF_BEGIN
@@ -902,7 +912,7 @@ hipError_t rt_launch_progressive_present(const float *pass_sum, uint32_t spp, ui
     return hipGetLastError();
 }
 
-// Header (work counter, diagnostics, camera) + the deep-stack columns of the largest grid.
+// Header (item counters, diagnostics, camera) + the deep-stack columns of the largest grid.
 size_t rt_fused_workspace_bytes(int cus) {
     return RT_FUSED_DEEP_OFFSET + (size_t)cus * 8u * RT_BLOCK * (RT_STACK_DEPTH - 16) * 4u;
 }
@@ -1011,6 +1021,9 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     n_chunks = (rc.spp + chunk_spp - 1u) / chunk_spp;
     uint32_t n_items = n_tiles * n_chunks;
     grid = (int)std::min<uint32_t>((uint32_t)grid, (n_items + RT_WAVES - 1u) / RT_WAVES);
+    // item counters: as many as there are workgroups to serve them, at most RT_ITEM_COUNTERS, a power of two
+    uint32_t counters_log2 = 0;
+    while ((2u << counters_log2) <= RT_ITEM_COUNTERS && (16u << counters_log2) <= (uint32_t)grid) counters_log2++;
     const bool prof = (knobs & 0x10000u) != 0;
     k_fused_setup<<<1, 256, 0, stream>>>(counter, cam);
     hipError_t e = hipGetLastError();
@@ -1018,9 +1031,9 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     const RtDevCamera *camp = (const RtDevCamera *)((const char *)counter + RT_FUSED_CAMERA_OFFSET);
     if (timer) timer->begin(stream);
     if (prof)
-        k_fused<FEAT, true, STACK, WPS, NODE16, DEEP, LIST><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u));
+        k_fused<FEAT, true, STACK, WPS, NODE16, DEEP, LIST><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u) | (counters_log2 << 8));
     else
-        k_fused<FEAT, false, STACK, WPS, NODE16, DEEP, LIST><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u));
+        k_fused<FEAT, false, STACK, WPS, NODE16, DEEP, LIST><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u) | (counters_log2 << 8));
     if (timer) timer->end(stream);
     return hipGetLastError();
 }
@@ -1079,7 +1092,7 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
 }
 
 // ------------------------------------------------------------------ render without a workspace argument
-// The fused kernel's scratch (work counter, diagnostics, camera, deep-stack columns) for callers
+// The fused kernel's scratch (item counters, diagnostics, camera, deep-stack columns) for callers
 // that cannot allocate device memory: one array per GPU, part of the loaded code object, held
 // until the process ends.  `scratch` is a host-side stand-in for the symbol, never a device
 // address: the address of each device's copy comes from hipGetSymbolAddress with that device

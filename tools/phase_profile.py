@@ -28,7 +28,7 @@ _nodes = {"auto": abi.RT_NODES_AUTO, "f32": abi.RT_NODES_F32, "f16": abi.RT_NODE
 r = Renderer(scene, w, h, profile_phases=True, nodes=_nodes, refill=int(_os.environ["RT_REFILL"]) if "RT_REFILL" in _os.environ else None)
 r.draw(spp, depth, seed)
 torch.cuda.synchronize()
-pc = r.workspace[256:256 + 96].cpu().numpy().view(np.uint64).reshape(4, 3)
+pc = r.workspace[1024:1024 + 96].cpu().numpy().view(np.uint64).reshape(4, 3)
 tot = pc[:, 2].sum()
 for nm, (ex, ln, cy) in zip(["shade", "raygen", "node", "leaf"], pc):
     print("%-7s execs %12d  lanes/exec %5.1f  cycles/exec %7.1f  cycle share %.3f" % (nm, ex, ln / max(ex, 1), cy / max(ex, 1), cy / tot))
