@@ -912,7 +912,8 @@ RT_DEV v2f slab_pair(uint32_t packed, float inv, float oid) {
 }
 template <int LDS_ENTRIES = 0>
 RT_DEV void trav_node16(const uint4 *nodes16, Trav &t, float tmin, uint32_t *stack, const DeepStack *deep = nullptr) {
-    const uint4 *n = nodes16 + 2u * t.cur;
+    // t.cur is the node's byte offset (references inside this array are stored that way, and so is the start)
+    const uint4 *n = (const uint4 *)((const char *)nodes16 + t.cur);
     uint4 a = n[0], b = n[1];
     const bool px = t.inv_d.x >= 0.0f, py = t.inv_d.y >= 0.0f, pz = t.inv_d.z >= 0.0f;
     // (left, right) entry and exit distances per axis; a NaN (inf - inf) is dropped by max3/min3

@@ -352,6 +352,10 @@ std::vector<uint32_t> pack_nodes16(const std::vector<float> &nodes) {
             o[2 * a + 1] = (uint32_t)half_toward(n[2 * a + 1], true) | ((uint32_t)half_toward(n[6 + 2 * a + 1], true) << 16);
         }
         memcpy(o + 6, n + 12, 8);
+        // a reference to an inner node is kept as that node's byte offset in this array: the kernel adds it to the
+        // array's address without a shift
+        for (int c = 6; c < 8; c++)
+            if (!(o[c] & RT_REF_LEAF)) o[c] *= 32u;
     }
     return out;
 }
@@ -1120,6 +1124,7 @@ int rt_scene_commit(RtScene *sc) {
             for (int k = 0; k < 12; k++)
                 if (std::isfinite(bld.nodes[i + k])) reach = std::max(reach, std::fabs(bld.nodes[i + k]));
         sc->use_nodes16 = sc->node_format == RT_NODES_F16 || (sc->node_format == RT_NODES_AUTO && reach <= 60000.f);
+        if (bld.nodes.size() / 16 >= (1u << 26)) sc->use_nodes16 = false;      // byte offsets of that form must stay below the leaf bit
         if (sc->use_nodes16) {
             std::vector<uint32_t> n16 = pack_nodes16(bld.nodes);
             if ((rc = upload(sc, n16, &d.nodes16)) < 0) return rc;

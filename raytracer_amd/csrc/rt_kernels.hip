@@ -720,7 +720,8 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
         RT_PROF_END(1, generating);
         if (start) {
             key = g.state;
-            trav_begin(t, s.root, o, d, RT_INF);
+            // the 32-byte node form walks byte offsets
+            trav_begin(t, (NODE16 && !(s.root & RT_REF_LEAF)) ? s.root * 32u : s.root, o, d, RT_INF);
         }
         const uint32_t n_paths = (uint32_t)__popcll(__ballot(has_path));
         if (n_paths == 0) {
