@@ -809,12 +809,38 @@ struct Trav {
     f3 o, d;
     f3 inv_d, oid;         // 1/d and -o/d
     uint32_t cur;
-    int sp;
+    uint32_t sp;           // LDS byte address of the lane's next free stack slot (slots lie RT_BLOCK words apart)
     Best best;
     bool found;
 };
 
-RT_DEV void trav_begin(Trav &t, uint32_t root, f3 o, f3 d, float tmax) {
+// The stack pointer is kept as an absolute LDS address, so a push or a pop is the access itself and one add.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+RT_DEV uint32_t lds_address(const uint32_t *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(uintptr_t)(const lds_u32 *)p;
+#else
+    return (uint32_t)(uintptr_t)p;
+#endif
+}
+RT_DEV uint32_t lds_load(uint32_t address) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const lds_u32 *)address;
+#else
+    return address;
+#endif
+}
+RT_DEV void lds_store(uint32_t address, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *(lds_u32 *)address = v;
+#else
+    (void)address; (void)v;
+#endif
+}
+#define RT_STACK_STEP (RT_BLOCK * 4u)      // bytes between a lane's consecutive stack entries
+
+// `stack`: the lane's entry 0.
+RT_DEV void trav_begin(Trav &t, uint32_t root, f3 o, f3 d, float tmax, const uint32_t *stack) {
     t.o = o; t.d = d;
     // A zero direction component would make plane*(1/d) - o*(1/d) an inf - inf; a component
     // of magnitude 2^-80 instead keeps the product form exact in sign and still puts
@@ -825,7 +851,7 @@ RT_DEV void trav_begin(Trav &t, uint32_t root, f3 o, f3 d, float tmax) {
     t.inv_d = mk3(rcp(ds.x), rcp(ds.y), rcp(ds.z));
     t.oid = mk3(-o.x * t.inv_d.x, -o.y * t.inv_d.y, -o.z * t.inv_d.z);
     t.cur = root;
-    t.sp = 0;
+    t.sp = lds_address(stack);
     t.best.t = tmax;
     t.best.ref = RT_REF_NONE;
     t.best.code = 0;
@@ -840,23 +866,25 @@ typedef __attribute__((address_space(1))) uint32_t global_u32;   // typed as glo
 struct DeepStack {
     global_u32 *column;    // already offset by the thread's index in the grid
     uint32_t stride;       // threads in the grid
+    uint32_t lds_limit;    // LDS address just behind the workgroup's LDS entries: a slot address below it is in LDS, and
+                           // (address - lds_limit) / RT_STACK_STEP is the entry's index in the column otherwise
 };
 template <int LDS_ENTRIES>
-RT_DEV void stack_put(uint32_t *stack, const DeepStack *deep, int sp, uint32_t v) {
-    if (LDS_ENTRIES == 0 || sp < LDS_ENTRIES) stack[sp * RT_BLOCK] = v;
-    else deep->column[(size_t)(sp - LDS_ENTRIES) * deep->stride] = v;
+RT_DEV void stack_put(const DeepStack *deep, uint32_t slot, uint32_t v) {
+    if (LDS_ENTRIES == 0 || slot < deep->lds_limit) lds_store(slot, v);
+    else deep->column[(size_t)((slot - deep->lds_limit) / RT_STACK_STEP) * deep->stride] = v;
 }
 template <int LDS_ENTRIES>
-RT_DEV uint32_t stack_get(const uint32_t *stack, const DeepStack *deep, int sp) {
-    if (LDS_ENTRIES == 0 || sp < LDS_ENTRIES) return stack[sp * RT_BLOCK];
-    return deep->column[(size_t)(sp - LDS_ENTRIES) * deep->stride];
+RT_DEV uint32_t stack_get(const DeepStack *deep, uint32_t slot) {
+    if (LDS_ENTRIES == 0 || slot < deep->lds_limit) return lds_load(slot);
+    return deep->column[(size_t)((slot - deep->lds_limit) / RT_STACK_STEP) * deep->stride];
 }
 
 template <int LDS_ENTRIES = 0>
 RT_DEV void trav_pop(Trav &t, const uint32_t *stack, const DeepStack *deep = nullptr) {
-    if (t.sp == 0) { t.cur = RT_REF_NONE; return; }
-    t.sp--;
-    t.cur = stack_get<LDS_ENTRIES>(stack, deep, t.sp);
+    if (t.sp == lds_address(stack)) { t.cur = RT_REF_NONE; return; }
+    t.sp -= RT_STACK_STEP;
+    t.cur = stack_get<LDS_ENTRIES>(deep, t.sp);
 }
 
 // Entry distance of the ray into one child box, and whether it is hit within
@@ -887,8 +915,8 @@ RT_DEV void trav_node(const float4 *nodes, Trav &t, float tmin, uint32_t *stack,
     hr = hr && rref != RT_REF_NONE;       // a single-object scene has no right child
     if (hl && hr) {
         bool left_first = tl <= tr;
-        stack_put<LDS_ENTRIES>(stack, deep, t.sp, left_first ? rref : lref);
-        t.sp++;
+        stack_put<LDS_ENTRIES>(deep, t.sp, left_first ? rref : lref);
+        t.sp += RT_STACK_STEP;
         t.cur = left_first ? lref : rref;
     } else if (hl) {
         t.cur = lref;
@@ -928,8 +956,8 @@ RT_DEV void trav_node16(const uint4 *nodes16, Trav &t, float tmin, uint32_t *sta
     hr = hr && rref != RT_REF_NONE;
     if (hl && hr) {
         bool left_first = tl <= tr;
-        stack_put<LDS_ENTRIES>(stack, deep, t.sp, left_first ? rref : lref);
-        t.sp++;
+        stack_put<LDS_ENTRIES>(deep, t.sp, left_first ? rref : lref);
+        t.sp += RT_STACK_STEP;
         t.cur = left_first ? lref : rref;
     } else if (hl) {
         t.cur = lref;
@@ -945,7 +973,7 @@ template <bool SIMPLE, bool MOTION = false, bool WIDE = false>
 RT_DEV bool trace(const RtDevScene &s, f3 o, f3 d, float tmin, float tmax, uint64_t volume_key,
                   const float *scripted, uint32_t n_scripted, uint32_t *stack, Best &best, float time = 0.0f) {
     Trav t;
-    trav_begin(t, s.root, o, d, tmax);
+    trav_begin(t, s.root, o, d, tmax, stack);
     const float4 *nodes = (const float4 *)s.nodes;
     while (t.cur != RT_REF_NONE) {
         while (!(t.cur & RT_REF_LEAF)) trav_node(nodes, t, tmin, stack);

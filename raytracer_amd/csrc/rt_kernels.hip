@@ -578,6 +578,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
     DeepStack deep_cols;
     deep_cols.column = (global_u32 *)(uintptr_t)(counter + RT_FUSED_DEEP_OFFSET / 4u) + blockIdx.x * RT_BLOCK + threadIdx.x;
     deep_cols.stride = gridDim.x * RT_BLOCK;
+    deep_cols.lds_limit = lds_address(stack_mem) + (uint32_t)LDS_ENTRIES * RT_STACK_STEP;
     const DeepStack *deep = DEEP ? &deep_cols : nullptr;
     __shared__ float tile_acc[RT_WAVES][192];
     constexpr bool SIMPLE = !(FEAT & RT_FEAT_XPRIM);
@@ -614,7 +615,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
     Pcg g;
     g.state = g.inc = 0;
     Trav t;
-    trav_begin(t, RT_REF_NONE, mk3(0, 0, 0), mk3(0, 0, 1), RT_INF);
+    trav_begin(t, RT_REF_NONE, mk3(0, 0, 0), mk3(0, 0, 1), RT_INF, stack);
     acc[lane] = 0.f; acc[lane + 64] = 0.f; acc[lane + 128] = 0.f;
     while (true) {
         // ---- shade phase: lanes whose traversal ended
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
         if (start) {
             key = g.state;
             // the 32-byte node form walks byte offsets
-            trav_begin(t, (NODE16 && !(s.root & RT_REF_LEAF)) ? s.root * 32u : s.root, o, d, RT_INF);
+            trav_begin(t, (NODE16 && !(s.root & RT_REF_LEAF)) ? s.root * 32u : s.root, o, d, RT_INF, stack);
         }
         const uint32_t n_paths = (uint32_t)__popcll(__ballot(has_path));
         if (n_paths == 0) {
