@@ -933,6 +933,17 @@ RT_DEV void trav_node(const float4 *nodes, Trav &t, float tmin, uint32_t *stack,
 // direction, so one select per word replaces the min/max pair per plane pair, and the
 // half -> float widening rides inside the FMA (v_fma_mix_f32).
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+// min(a, b) as the one instruction.  fminf() first quiets a possible signalling NaN in an operand the compiler cannot
+// see the origin of (the closest distance so far, carried round the loop): one more instruction in every node step.
+RT_DEV float min_raw(float a, float b) {
+    float r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+#else
+    r = a < b ? a : b;
+#endif
+    return r;
+}
 RT_DEV v2f slab_pair(uint32_t packed, float inv, float oid) {
     v2h h = __builtin_bit_cast(v2h, packed);
     v2f r = {fmaf((float)h.x, inv, oid), fmaf((float)h.y, inv, oid)};
@@ -950,10 +961,11 @@ RT_DEV void trav_node16(const uint4 *nodes16, Trav &t, float tmin, uint32_t *sta
     v2f nz = slab_pair(pz ? b.x : b.y, t.inv_d.z, t.oid.z), fz = slab_pair(pz ? b.y : b.x, t.inv_d.z, t.oid.z);
     float limit = t.best.t;
     float tl = fmaxf(fmaxf(nx.x, ny.x), fmaxf(nz.x, tmin)), tr = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, tmin));
-    float el = fminf(fminf(fx.x, fy.x), fminf(fz.x, limit)), er = fminf(fminf(fx.y, fy.y), fminf(fz.y, limit));
+    float el = fminf(fminf(fx.x, fy.x), min_raw(fz.x, limit)), er = fminf(fminf(fx.y, fy.y), min_raw(fz.y, limit));
     bool hl = tl <= el, hr = tr <= er;
     uint32_t lref = b.z, rref = b.w;
-    hr = hr && rref != RT_REF_NONE;
+    // (an absent right child - the only node of a one-object scene - needs no test here: its box is the empty one,
+    // +inf .. -inf, and with the near and far planes picked by the ray's signs no ray enters it)
     if (hl && hr) {
         bool left_first = tl <= tr;
         stack_put<LDS_ENTRIES>(deep, t.sp, left_first ? rref : lref);
