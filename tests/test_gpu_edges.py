@@ -160,6 +160,28 @@ def test_list_and_tree_traversal_render_the_same_image(ctx, name):
     assert close > 0.999
 
 
+@pytest.mark.parametrize("nodes", [abi.RT_NODES_F16, abi.RT_NODES_F32], ids=["half_nodes", "float_nodes"])
+def test_one_object_scene_through_the_tree_kernels(ctx, nodes):
+    """A scene of one sphere is a tree of one node whose right child is absent (an empty box, +inf .. -inf):
+    walked by the tree kernels in both node forms it gives the image of the list walk and the oracle's."""
+    from raytracer_amd.renderer import Renderer
+    scene = Scene(CameraConfig(vertical_fov=40, look_from=(0, 0.5, 4), look_at=(0, 0, 0)), [Sphere((0.2, 0, 0), 1.0, ColoredLambertian((0.8, 0.4, 0.3)))])
+    w, h, spp, depth, seed = 96, 64, 8, 10, 5
+    imgs = []
+    for traversal in (abi.RT_TRAVERSAL_TREE, abi.RT_TRAVERSAL_LIST):
+        r = Renderer(scene, w, h, ctx=ctx, traversal=traversal, nodes=nodes)
+        assert r.native.stats()["n_objects"] == 1 and r.native.stats()["n_nodes"] == 1
+        r.draw(spp, depth, seed)
+        torch.cuda.synchronize()
+        imgs.append(r.mean().cpu().numpy().astype(np.float64))
+    orc = ob.oracle_scene_from(scene)
+    ref, _, _ = orc.render(scene.camera, RenderConfig(spp, depth, 1, seed, 0), w, h, precision=ob.ORC_F64)
+    ref = ref / spp
+    for img in imgs:
+        assert img.sum() > 0 and (np.abs(img - ref) <= 1e-3).mean() > 0.995
+    assert (np.abs(imgs[0] - imgs[1]) <= 1e-5).mean() > 0.999
+
+
 @pytest.mark.parametrize("size,spp", [((37, 19), 1), ((5, 3), 7), ((64, 8), 3), ((131, 77), 33)])
 def test_ragged_images_and_odd_sample_counts(ctx, size, spp):
     """Partial 8x8 tiles, fewer pixels than one tile, sample counts that do not divide into
