@@ -1366,12 +1366,13 @@ int rt_band_rows(int height, int band_index, int band_count) {
 namespace {
 
 // Knobs of the fused kernel: node steps go on while 8 lanes want one.  Sphere tests cost about
-// one node step, so in sphere scenes 20 lanes waiting at a leaf get their turn even then; tests
+// one node step, so in sphere scenes 12 lanes waiting at a leaf get their turn even then (swept 8..64; 20 when the
+// spheres move: the change of frame makes their test dearer); tests
 // of cylinders, boxes, CSG shapes and volumes cost several node steps and wait for fuller waves.
 uint32_t fused_knobs(const RtScene *sc, const RtDevCamera &cam) {
     const uint32_t node_min = sc->node_min >= 0 ? (uint32_t)sc->node_min : 8u;
     return sc->refill | (node_min << 8) | (sc->profile_phases ? 0x10000u : 0u) | (sc->use_nodes16 ? 0x20000u : 0u) |
-           ((cam.defocus ? 16u : 0u) << 18) | (((sc->feat & 1u) ? 65u : 20u) << 25);
+           ((cam.defocus ? 16u : 0u) << 18) | (((sc->feat & RT_FEAT_XPRIM) ? 65u : ((sc->feat & RT_FEAT_MOTION) ? 20u : 12u)) << 25);
 }
 
 uint32_t fused_knobs2(const RtScene *sc) {
