@@ -34,7 +34,9 @@
 #ifndef RT_WPS_MOVING_SPHERES
 #define RT_WPS_MOVING_SPHERES 6   // ... of the spheres-and-moving-spheres kernel
 #endif
+#ifndef RT_DOUBLE_STEP
 #define RT_DOUBLE_STEP 24u       // lanes on inner nodes from which a second node step follows the first without a new count (+1.6 % on random spheres)
+#endif
 #define RT_T_MIN 1e-3f          // Camera.swift:117
 #define RT_WAVES (RT_BLOCK / 64)
 
