@@ -23,7 +23,9 @@
 #ifndef RT_WPS0
 #define RT_WPS0 8              // waves per SIMD of the spheres-only kernel (64 VGPRs)
 #endif
+#ifndef RT_WPS_DEEP
 #define RT_WPS_DEEP 7          // ... of its deep-tree form: 72 VGPRs, measured +5 % on the million-sphere workload over 8 (6: +-0)
+#endif
 #ifndef RT_WPS_XPRIM
 #define RT_WPS_XPRIM 4         // ... of the tree kernels of scenes with cylinders, boxes, quads, CSG shapes or volumes: 128 VGPRs, no scratch;
                                // left free the textured one takes 137 registers and runs at 3 waves, 14 % slower on the CSG / textured workload
