@@ -390,8 +390,6 @@ struct Builder {
         return mid;
     }
 
-    // Binned surface-area heuristic (16 bins per axis on the box centres): minimises
-    // area(left)*count(left) + area(right)*count(right).  Returns lo when no split helps.
     // Surface-area split over every position of the centroid order on each axis (small ranges: an exact sweep
     // costs nothing there and the bottom levels of the tree are where most node visits go).
     size_t split_sah_sweep(size_t lo, size_t hi) {
@@ -419,6 +417,8 @@ struct Builder {
         return lo + best_pos;
     }
 
+    // Binned surface-area heuristic (16 bins per axis on the box centres): minimises
+    // area(left)*count(left) + area(right)*count(right).  Returns lo when no split helps.
     size_t split_sah(size_t lo, size_t hi) {
         if (hi - lo <= sweep_below) return split_sah_sweep(lo, hi);
         constexpr int BINS = 16;
