@@ -1073,18 +1073,28 @@ RT_DEV void complete_hit(const RtDevScene &s, Best best, f3 o, f3 d, bool want_u
     } else if (kind != RT_KIND_CDV && !moved) {
         object = skind == RT_KIND_SPHERE ? s.sphere_obj[sidx] : s.xprim_obj[sidx];
     }
-    float t_surface = best.t;
-    if (scatter) {
-        // RenderableImpl.h:760-766: point on the ray, normal against the ray, material and texture
-        // coordinates of the ENTRY hit of the interval, which lies on leaf_ref at its entry or exit
-        Span sp = prim_span(s, leaf_ref, o, d);
-        t_surface = ((best.code >> RT_CODE_LEAF_EXIT_SHIFT) & 1u) ? sp.t1 : sp.t0;
-    }
+    // A scatter inside a medium takes the ray's own direction for its normal; only its texture coordinates come
+    // from the surface (those of the ENTRY hit of the interval, RenderableImpl.h:760-766), so a medium whose
+    // material reads none needs neither the entry distance nor the surface.
+    bool surface_uv = want_uv || scatter;
     if (by_material) {
         *m_out = load_material(s, prim_material(s, leaf_ref, best.code & 7u));
-        want_uv = want_uv && material_wants_uv(m_out->kind);
+        surface_uv = want_uv && material_wants_uv(m_out->kind);
     }
-    Surface sf = prim_surface(s, leaf_ref, best.code & 7u, o, d, t_surface, want_uv || scatter);
+    Surface sf;
+    if (scatter && !surface_uv) {
+        sf.normal = mk3(0.0f, 0.0f, 0.0f);
+        sf.u = sf.v = 0.0f;
+        sf.material = prim_material(s, leaf_ref, best.code & 7u);
+    } else {
+        float t_surface = best.t;
+        if (scatter) {
+            // the entry hit lies on leaf_ref at its entry or exit
+            Span sp = prim_span(s, leaf_ref, o, d);
+            t_surface = ((best.code >> RT_CODE_LEAF_EXIT_SHIFT) & 1u) ? sp.t1 : sp.t0;
+        }
+        sf = prim_surface(s, leaf_ref, best.code & 7u, o, d, t_surface, surface_uv);
+    }
     if (flip) sf.normal = -sf.normal;
     if (scatter) sf.normal = -d;
     if (MOTION && moved) sf.normal = frame_out(frame, sf.normal);
