@@ -367,7 +367,8 @@ RT_DEV Surface prim_surface(const RtDevScene &s, uint32_t ref, uint32_t tag, f3 
             r.normal = x.c1 * flip;
             r.material = mats[tag];
             float inv2r = rcp(2.0f * radius);
-            if (s.kit_convention) {            // Hittable.swift:245,248: (x, z) on both caps
+            if (!want_uv) {
+            } else if (s.kit_convention) {            // Hittable.swift:245,248: (x, z) on both caps
                 r.u = fmaf(lp.x, inv2r, 0.5f);
                 r.v = fmaf(lp.z, inv2r, 0.5f);
             } else {                           // RenderableImpl.h:113-121
@@ -382,6 +383,7 @@ RT_DEV Surface prim_surface(const RtDevScene &s, uint32_t ref, uint32_t tag, f3 
         f3 col = axis == 0u ? x.c0 : (axis == 1u ? x.c1 : x.c2);
         r.normal = (tag & 1u) ? col : -col;
         r.material = mats[tag];
+        if (!want_uv) return r;
         f3 lp = rot_t(x, p - x.t) * mk3(rcp(x.p0), rcp(x.p1), rcp(x.p2));
         switch (tag) {
         case 0: r.u = 1.0f - lp.z; r.v = lp.y; break;          // left
@@ -396,9 +398,11 @@ RT_DEV Surface prim_surface(const RtDevScene &s, uint32_t ref, uint32_t tag, f3 
     // quad
     r.normal = mk3(x.p0, x.p1, x.p2);
     r.material = mats[0];
-    f3 q = p - x.c0;
-    r.u = dot(x.c1, q);
-    r.v = dot(x.c2, q);
+    if (want_uv) {
+        f3 q = p - x.c0;
+        r.u = dot(x.c1, q);
+        r.v = dot(x.c2, q);
+    }
     return r;
 }
 
