@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -17,6 +18,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/raytracer_amd.h"
@@ -363,7 +365,7 @@ std::vector<uint32_t> pack_nodes16(const std::vector<float> &nodes) {
 struct Builder {
     std::vector<BuildItem> items;
     std::vector<float> nodes;      // 16 floats per node
-    uint32_t max_depth = 0;
+    std::atomic<uint32_t> max_depth{0};
     size_t sweep_below = 0;        // ranges of at most this many items are split by an exact sweep instead of bins
     bool sah = false;
     uint32_t depth_limit = RT_STACK_DEPTH;   // small scenes are kept within 16 levels: the 16-entry-stack kernel holds more waves
@@ -468,13 +470,31 @@ struct Builder {
         return (size_t)(mid - items.begin());
     }
 
-    // Builds the subtree over items[lo, hi); returns its reference and box.
-    uint32_t build(size_t lo, size_t hi, Box3 &box, uint32_t depth) {
+    // A subtree over n items has exactly n - 1 inner nodes, so the place of every node in pre-order (node, left
+    // subtree, right subtree) is known before its subtree is built: the node of a range is `idx`, its left subtree
+    // starts at idx + 1 and its right subtree at idx + (mid - lo).  Both halves of a large range can therefore be
+    // built by different threads into the same array, and the result is the one a single thread writes.
+    static constexpr size_t PAR_MIN_ITEMS = 32768;
+    static constexpr uint32_t PAR_LEVELS = 4;      // at most 2^4 ranges in flight
+
+    void note_depth(uint32_t d) {
+        uint32_t seen = max_depth.load(std::memory_order_relaxed);
+        while (d > seen && !max_depth.compare_exchange_weak(seen, d, std::memory_order_relaxed)) {}
+    }
+
+    // Builds the whole tree; returns the root's reference.
+    uint32_t build_all(Box3 &box) {
+        nodes.assign(16 * (items.size() - 1), 0.f);
+        return build(0, items.size(), box, 0, 0);
+    }
+
+    // Builds the subtree over items[lo, hi) with its root at node `idx`; returns its reference and box.
+    uint32_t build(size_t lo, size_t hi, Box3 &box, uint32_t depth, uint32_t idx) {
         if (hi - lo == 1) {
             box = items[lo].box;
             return RT_REF_LEAF | items[lo].ref;
         }
-        max_depth = std::max(max_depth, depth + 1);
+        note_depth(depth + 1);
         Box3 all;
         for (size_t i = lo; i < hi; i++) all.add(items[i].box);
         size_t mid = lo;
@@ -486,11 +506,17 @@ struct Builder {
             if (depth + 2 + need < depth_limit) mid = split_sah(lo, hi);
         }
         if (mid == lo || mid == hi) mid = split_median(lo, hi, all);
-        uint32_t idx = (uint32_t)(nodes.size() / 16);
-        nodes.resize(nodes.size() + 16, 0.f);
         Box3 lb, rb;
-        uint32_t l = build(lo, mid, lb, depth + 1);
-        uint32_t r = build(mid, hi, rb, depth + 1);
+        uint32_t l, r;
+        const uint32_t left_idx = idx + 1, right_idx = idx + (uint32_t)(mid - lo);
+        if (depth < PAR_LEVELS && hi - lo >= PAR_MIN_ITEMS) {
+            std::thread other([&] { l = build(lo, mid, lb, depth + 1, left_idx); });
+            r = build(mid, hi, rb, depth + 1, right_idx);
+            other.join();
+        } else {
+            l = build(lo, mid, lb, depth + 1, left_idx);
+            r = build(mid, hi, rb, depth + 1, right_idx);
+        }
         float *n = nodes.data() + 16 * (size_t)idx;
         put_box(n, lb);
         put_box(n + 6, rb);
@@ -1127,7 +1153,7 @@ int rt_scene_commit(RtScene *sc) {
         bld.max_depth = 1;
     } else if (bld.items.size() > 1) {
         Box3 all;
-        root = bld.build(0, bld.items.size(), all, 0);
+        root = bld.build_all(all);
     }
     if (bld.max_depth > RT_STACK_DEPTH) return fail(RT_ERR_LIMIT, "BVH deeper than the traversal stack");
 
