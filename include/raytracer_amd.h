@@ -278,7 +278,9 @@ int rt_add_object(RtScene *, int shape);
  * index of the first sphere. */
 int rt_add_sphere_objects(RtScene *, int n, const float *center_radius, const uint32_t *material_offsets);
 /* Acceleration-structure build + upload (SceneBuffers.swift:42-71;
- * BoundingVolumeNode.init, RayTracingKit/Hittable.swift:609-631). */
+ * BoundingVolumeNode.init, RayTracingKit/Hittable.swift:609-631).  Scenes of 32768 objects
+ * or more are built with up to 15 helper threads that end before the call returns; the tree
+ * does not depend on how many of them could be started. */
 int rt_scene_commit(RtScene *);
 int rt_scene_stats(const RtScene *, RtSceneStats *out);
 

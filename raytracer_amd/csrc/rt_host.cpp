@@ -18,6 +18,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -509,14 +510,14 @@ struct Builder {
         Box3 lb, rb;
         uint32_t l, r;
         const uint32_t left_idx = idx + 1, right_idx = idx + (uint32_t)(mid - lo);
+        std::thread other;
         if (depth < PAR_LEVELS && hi - lo >= PAR_MIN_ITEMS) {
-            std::thread other([&] { l = build(lo, mid, lb, depth + 1, left_idx); });
-            r = build(mid, hi, rb, depth + 1, right_idx);
-            other.join();
-        } else {
-            l = build(lo, mid, lb, depth + 1, left_idx);
-            r = build(mid, hi, rb, depth + 1, right_idx);
+            // a process that may start no more threads builds this range on the one it has
+            try { other = std::thread([&] { l = build(lo, mid, lb, depth + 1, left_idx); }); } catch (const std::system_error &) {}
         }
+        if (!other.joinable()) l = build(lo, mid, lb, depth + 1, left_idx);
+        r = build(mid, hi, rb, depth + 1, right_idx);
+        if (other.joinable()) other.join();
         float *n = nodes.data() + 16 * (size_t)idx;
         put_box(n, lb);
         put_box(n + 6, rb);

@@ -386,6 +386,27 @@ def test_sphere_cloud_bulk_entry_point(ctx):
     assert (g["material_offset"][hit] == r["material_offset"][hit]).all()
 
 
+@pytest.mark.parametrize("builder", [abi.RT_BVH_SAH, abi.RT_BVH_MEDIAN_SPLIT])
+def test_threaded_tree_build_repeats_itself(ctx, builder):
+    """Scenes of 32768 objects or more are built by several host threads into one node array whose
+    places are fixed before the subtrees exist: two commits of one scene must give the same tree, so
+    first hits (object and the bits of t) are equal whatever the threads' timing was."""
+    from raytracer_amd.renderer import NativeScene, camera_rays
+    cloud = scenes.SphereCloud(150_000, 7)
+    rays = camera_rays(ctx, cloud.camera, RenderConfig(1, 1, 1, 7, 0), 160, 90).astype(np.float32)
+    runs = []
+    for _ in range(2):
+        nat = NativeScene(ctx)
+        cloud.encode(nat)
+        nat.set_option(abi.RT_OPTION_BVH_BUILDER, builder)
+        nat.commit()
+        runs.append((nat.stats(), nat.first_hit(rays)))
+    (s0, h0), (s1, h1) = runs
+    assert s0 == s1 and s0["n_nodes"] == 149_999 and s0["bvh_depth"] <= 24
+    assert (h0["object"] == h1["object"]).all() and (h0["object"] >= 0).sum() > 1000
+    assert (h0["t"].view(np.uint32) == h1["t"].view(np.uint32)).all()
+
+
 def test_sphere_cloud_image_against_the_oracle(ctx):
     """Tiny spheres far apart scatter like a dispersing billiard: a float rounding of the hit point
     is a different path two bounces later, so per-pixel agreement with the double oracle is only
