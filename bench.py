@@ -47,27 +47,83 @@ def host_threads():
     return max(1, n)
 
 
+# Sample of each workload the CPU leg renders (and the GPU renders again after the timed region, for the
+# PSNR): the whole image at a quarter of the pixels for the 1080p workloads; for the million-sphere workload
+# a window of the 4K image at few samples, because the oracle walks the reference's median-split tree there
+# (1535 box tests per sample) and builds it on one thread.
+def baseline_sample(name, w, h):
+    if name.startswith("cfg5"):
+        return {"width": w, "height": h, "window": (w // 2 - 320, h // 2 - 180, 640, 360), "spp": 8}
+    return {"width": min(w, 960), "height": min(h, 540), "window": None, "spp": 256}
+
+
 def cpu_baseline(name):
     """The CPU oracle (double precision restatement of the reference renderer) timed on a
-    bounded sample of the same workload: the same scene at 960x540, 256 spp."""
+    bounded sample of the same workload.  Returns (record, mean image of the sample)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_bridge as ob
     from raytracer_amd import scenes
     from raytracer_amd.scene import RenderConfig
-    if name.startswith("cfg5"):
-        return None             # building the million-sphere oracle tree alone takes longer than the bench
     scene, w, h, spp, depth, seed = scenes.make_workload(name)
-    orc = ob.oracle_scene_from(scene)
-    cw, ch, cspp = min(w, 960), min(h, 540), 256
-    threads = host_threads()
-    orc.render(scene.camera, RenderConfig(1, depth, 1, seed, 0), cw, ch, threads=threads)      # warm
+    smp = baseline_sample(name, w, h)
     t0 = time.perf_counter()
-    _, used, _ = orc.render(scene.camera, RenderConfig(cspp, depth, 1, seed, 0), cw, ch, precision=ob.ORC_F64, threads=threads)
+    orc = ob.oracle_scene_from(scene)
+    build_s = time.perf_counter() - t0
+    cw, ch, cspp, win = smp["width"], smp["height"], smp["spp"], smp["window"]
+    threads = host_threads()
+    orc.render(scene.camera, RenderConfig(1, depth, 1, seed, 0), cw, ch, window=(0, 0, 64, 36), threads=threads)      # warm
+    t0 = time.perf_counter()
+    img, used, _ = orc.render(scene.camera, RenderConfig(cspp, depth, 1, seed, 0), cw, ch, window=win, precision=ob.ORC_F64, threads=threads)
     dt = time.perf_counter() - t0
-    return {"value": cw * ch * cspp / dt / 1e6, "unit": "Msamples/s", "cores": used, "kind": "port",
-            "host_cpus_visible": os.cpu_count(),
-            "sample": "%s scene at %dx%d, %d spp, depth %d, f64, %.1f s on %d threads (the job's CPU share; the host shows %d CPUs)"
-                      % (name, cw, ch, cspp, depth, dt, used, os.cpu_count() or 0)}
+    n = (win[2] * win[3] if win else cw * ch) * cspp
+    where = "a %dx%d window of the %dx%d image" % (win[2], win[3], cw, ch) if win else "%dx%d" % (cw, ch)
+    rec = {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": used, "kind": "port",
+           "host_cpus_visible": os.cpu_count(),
+           "sample": "%s scene at %s, %d spp, depth %d, f64, %.1f s on %d threads (the job's CPU share; the host shows %d CPUs); "
+                     "scene flattening and the reference's tree build took another %.1f s on one thread, not counted"
+                     % (name, where, cspp, depth, dt, used, os.cpu_count() or 0, build_s)}
+    return rec, img / cspp
+
+
+def psnr_against(ref, r, name, w, h, depth, seed):
+    """Mean radiance of the HIP path on the CPU leg's sample (same scene, same seed, same sample
+    indices: both sides draw sample s of pixel (x, y) from the same stream) against the oracle's image."""
+    import numpy as np
+    import torch
+    from raytracer_amd.renderer import Renderer
+    smp = baseline_sample(name, w, h)
+    g = Renderer(r.scene, smp["width"], smp["height"], native=r.native)
+    g.draw(smp["spp"], depth, seed, first_sample=0)
+    torch.cuda.synchronize()
+    got = g.mean().cpu().numpy().astype(np.float64)
+    if smp["window"]:
+        x0, y0, ww, wh = smp["window"]
+        got = got[y0:y0 + wh, x0:x0 + ww]
+    a, b = np.minimum(got, 4.0), np.minimum(ref, 4.0)        # clipped like a display would
+    mse = float(np.mean((a - b) ** 2))
+    return {"psnr_db": 10 * np.log10(1.0 / max(mse, 1e-30)), "rmse": float(np.sqrt(mse)),
+            "mean_rel_diff": float(abs(got.mean() - ref.mean()) / max(ref.mean(), 1e-12)),
+            "pixels_equal_1e-3": float(np.mean(np.max(np.abs(got - ref), axis=2) <= 1e-3 * np.maximum(1.0, np.max(ref, axis=2)))),
+            "against": "CPU oracle (f64) on the cpu_baseline sample, pre-gamma mean radiance clipped at 4, same seed and sample indices"}
+
+
+def counter_record(name):
+    """Lanes per vector instruction and vector-pipe occupancy of the dominant kernel, from the shader-engine counter
+    passes kept under profiles/ (rocprofv3 --pmc cannot run inside this process)."""
+    path = os.path.join(ROOT, "profiles", "pmc_sq_%s.json" % name)
+    if not os.path.exists(path):
+        return None
+    c = json.load(open(path))
+    try:
+        simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4       # the counter is summed over the 8 XCDs
+        return {"lanes_per_valu_inst": c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"],
+                # a wave64 instruction occupies the 16-lane pipe for 4 cycles
+                "valu_busy": 4.0 * c["SQ_INSTS_VALU"] / simd_cycles,
+                "wave_time_waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+                "spp_per_launch_of_the_counter_run": c.get("_spp"),
+                "source": "profiles/pmc_sq_%s.json" % name}
+    except (KeyError, ZeroDivisionError):
+        return None
 
 
 def parse_args():
@@ -91,14 +147,9 @@ def parse_args():
 
 def start_ranks(args):
     """`python bench.py --gpus N` without a launcher: this process starts the N ranks and
-    forwards rank 0's line.  Nothing here initialises a GPU (device_count does not)."""
-    import torch
+    forwards rank 0's line.  Nothing here asks the runtime anything about GPUs: each rank checks
+    for itself that its device exists (exit code 2 when it does not)."""
     from raytracer_amd import dist as rdist
-    backend = os.environ.get("RT_DIST_BACKEND", "nccl")
-    have = torch.cuda.device_count()
-    if backend == "nccl" and have < args.gpus:
-        print("bench.py: --gpus %d asked for but only %d GPU(s) are visible" % (args.gpus, have), file=sys.stderr)
-        return 2
     code, out = rdist.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
     sys.stdout.write(out)
     sys.stdout.flush()
@@ -126,7 +177,11 @@ def main():
 
     # RT_DIST_BACKEND=gloo lets the multi-rank path be rehearsed where the ranks share one GPU
     backend = os.environ.get("RT_DIST_BACKEND", "nccl")
-    local_rank %= max(1, torch.cuda.device_count())
+    have = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= have:
+        print("bench.py: rank %d of --gpus %d has no GPU (%d visible)" % (rank, args.gpus, have), file=sys.stderr)
+        sys.exit(2)
+    local_rank %= max(1, have)
     # RT_FORCE_DIST=1 takes the collective path with a single rank too (a check that RCCL initialises
     # and reduces next to the HIP library on a one-GPU box)
     use_dist = world > 1 or bool(os.environ.get("RT_FORCE_DIST"))
@@ -253,14 +308,21 @@ def main():
                 ex = json.load(open(efile))
                 roof["executed_flops_per_sample"] = ex["executed_flops_per_sample"]
                 roof["frac_executed"] = ex["executed_flops_per_sample"] * samples_launch / (k_ms / k_n * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS
+            cr = counter_record(args.workload)
+            if cr and k_name == "k_fused":
+                roof["counters"] = cr
             out["roofline"] = roof
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.workload)
-            if cb:
-                out["cpu_baseline"] = cb
+        if not args.no_cpu_baseline:
+            # after the timed region, on rank 0 only: the other ranks wait at the last barrier
+            cb, ref = cpu_baseline(args.workload)
+            out["cpu_baseline"] = cb
+            par = psnr_against(ref, r, args.workload, w, h, depth, seed)
+            out["psnr_db"] = par["psnr_db"]
+            out["parity"] = par
         print(json.dumps(out), flush=True)
     faulthandler.cancel_dump_traceback_later()
     if use_dist:
+        dist.barrier()          # the other ranks stay until rank 0 has finished its CPU leg
         dist.destroy_process_group()
 
 

@@ -399,8 +399,12 @@ int rt_render(RtScene *, const RtCameraConfig *, const RtRenderConfig *, uint32_
  * forbid hipMalloc.  The kernel's scratch (work counter, camera, deep traversal-stack columns:
  * 16 MiB + 4 KiB) is an array inside the library, one copy per GPU, resolved when
  * rt_context_create runs on that GPU and held until the process ends.  The call itself makes no
- * hipMalloc / hipFree, creates no events (rt_kernel_time does not see it) and queries nothing
- * from the runtime (rt_scene_commit has asked already); the caller still passes the accumulator.
+ * hipMalloc / hipFree, creates no events (rt_kernel_time does not see it), never synchronises and
+ * asks the runtime for nothing but the current device (hipGetDevice, and hipSetDevice there and back
+ * when the caller's current device is not the scene's; the occupancy query was made by
+ * rt_scene_commit): two kernel launches on `stream` are all it does, so it may be recorded into a
+ * HIP graph, whose replays render the camera and configuration given at capture time.  The caller
+ * still passes the accumulator.
  * Limits: those of rt_render (an image beyond 65535 pixels a side or 2^28 pixels is refused with
  * RT_ERR_LIMIT); on a GPU with more than 256 compute units the grid is sized for 256.
  * Every call on one GPU shares that GPU's array: calls that overlap on one GPU (two streams, two

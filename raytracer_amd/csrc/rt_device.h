@@ -873,22 +873,24 @@ struct DeepStack {
     uint32_t lds_limit;    // LDS address just behind the workgroup's LDS entries: a slot address below it is in LDS, and
                            // (address - lds_limit) / RT_STACK_STEP is the entry's index in the column otherwise
 };
-template <int LDS_ENTRIES>
+// STEP: bytes between a lane's consecutive stack entries = 4 x the threads of the workgroup (RT_STACK_STEP for the
+// 256-thread workgroups of most kernels).
+template <int LDS_ENTRIES, uint32_t STEP = RT_STACK_STEP>
 RT_DEV void stack_put(const DeepStack *deep, uint32_t slot, uint32_t v) {
     if (LDS_ENTRIES == 0 || slot < deep->lds_limit) lds_store(slot, v);
-    else deep->column[(size_t)((slot - deep->lds_limit) / RT_STACK_STEP) * deep->stride] = v;
+    else deep->column[(size_t)((slot - deep->lds_limit) / STEP) * deep->stride] = v;
 }
-template <int LDS_ENTRIES>
+template <int LDS_ENTRIES, uint32_t STEP = RT_STACK_STEP>
 RT_DEV uint32_t stack_get(const DeepStack *deep, uint32_t slot) {
     if (LDS_ENTRIES == 0 || slot < deep->lds_limit) return lds_load(slot);
-    return deep->column[(size_t)((slot - deep->lds_limit) / RT_STACK_STEP) * deep->stride];
+    return deep->column[(size_t)((slot - deep->lds_limit) / STEP) * deep->stride];
 }
 
-template <int LDS_ENTRIES = 0>
+template <int LDS_ENTRIES = 0, uint32_t STEP = RT_STACK_STEP>
 RT_DEV void trav_pop(Trav &t, const uint32_t *stack, const DeepStack *deep = nullptr) {
     if (t.sp == lds_address(stack)) { t.cur = RT_REF_NONE; return; }
-    t.sp -= RT_STACK_STEP;
-    t.cur = stack_get<LDS_ENTRIES>(deep, t.sp);
+    t.sp -= STEP;
+    t.cur = stack_get<LDS_ENTRIES, STEP>(deep, t.sp);
 }
 
 // Entry distance of the ray into one child box, and whether it is hit within
@@ -902,7 +904,7 @@ RT_DEV float box_entry(v2f tx, v2f ty, v2f tz, float tmin, float limit, bool &hi
 }
 
 // One inner-node step: tests both children, goes to the nearer one, pushes the farther.
-template <int LDS_ENTRIES = 0>
+template <int LDS_ENTRIES = 0, uint32_t STEP = RT_STACK_STEP>
 RT_DEV void trav_node(const float4 *nodes, Trav &t, float tmin, uint32_t *stack, const DeepStack *deep = nullptr) {
     const float4 *n = nodes + 4u * t.cur;
     float4 a = n[0], b = n[1], c = n[2], e = n[3];
@@ -919,15 +921,15 @@ RT_DEV void trav_node(const float4 *nodes, Trav &t, float tmin, uint32_t *stack,
     hr = hr && rref != RT_REF_NONE;       // a single-object scene has no right child
     if (hl && hr) {
         bool left_first = tl <= tr;
-        stack_put<LDS_ENTRIES>(deep, t.sp, left_first ? rref : lref);
-        t.sp += RT_STACK_STEP;
+        stack_put<LDS_ENTRIES, STEP>(deep, t.sp, left_first ? rref : lref);
+        t.sp += STEP;
         t.cur = left_first ? lref : rref;
     } else if (hl) {
         t.cur = lref;
     } else if (hr) {
         t.cur = rref;
     } else {
-        trav_pop<LDS_ENTRIES>(t, stack, deep);
+        trav_pop<LDS_ENTRIES, STEP>(t, stack, deep);
     }
 }
 
@@ -936,9 +938,6 @@ RT_DEV void trav_node(const float4 *nodes, Trav &t, float tmin, uint32_t *stack,
 // 6, 7 the refs.  Which word holds the near planes depends only on the sign of the ray
 // direction, so one select per word replaces the min/max pair per plane pair, and the
 // half -> float widening rides inside the FMA (v_fma_mix_f32).
-#ifndef RT_NODE_LATE_HALF
-#define RT_NODE_LATE_HALF 0
-#endif
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 // min(a, b) as the one instruction.  fminf() first quiets a possible signalling NaN in an operand the compiler cannot
 // see the origin of (the closest distance so far, carried round the loop): one more instruction in every node step.
@@ -956,34 +955,29 @@ RT_DEV v2f slab_pair(uint32_t packed, float inv, float oid) {
     v2f r = {fmaf((float)h.x, inv, oid), fmaf((float)h.y, inv, oid)};
     return r;
 }
-template <int LDS_ENTRIES = 0>
-RT_DEV void trav_node16(const uint4 *nodes16, Trav &t, float tmin, uint32_t *stack, const DeepStack *deep = nullptr) {
+typedef __attribute__((address_space(3))) uint4 lds_u4;
+// TOP_BYTES > 0: the first TOP_BYTES of the node array (the nodes with the largest boxes, which the builder of a large
+// tree puts first) also sit in LDS at byte address `top_lds`; a lane standing on one of them reads it from there.  The
+// vector L1 takes one lane's address per cycle and a 32-byte node is two of them, which is what bounds the walk of a
+// large tree; a node read from LDS costs that unit nothing.
+template <int LDS_ENTRIES = 0, uint32_t STEP = RT_STACK_STEP, uint32_t TOP_BYTES = 0>
+RT_DEV void trav_node16(const uint4 *nodes16, Trav &t, float tmin, uint32_t *stack, const DeepStack *deep = nullptr, uint32_t top_lds = 0) {
     // t.cur is the node's byte offset (references inside this array are stored that way, and so is the start)
     const uint4 *n = (const uint4 *)((const char *)nodes16 + t.cur);
     const bool px = t.inv_d.x >= 0.0f, py = t.inv_d.y >= 0.0f, pz = t.inv_d.z >= 0.0f;
     float limit = t.best.t;
-#if RT_NODE_LATE_HALF
-    // Measured and left off: the second half of the node (z planes, references) is asked for only by lanes whose ray
-    // passes the x and y slabs of at least one child - fewer addresses for the vector L1, but the second load then
-    // waits for the first: million spheres 0.93 -> 0.58 Gsamples/s, random spheres 12.9 -> 10.2.
-    uint4 a = n[0];
-    v2f nx = slab_pair(px ? a.x : a.y, t.inv_d.x, t.oid.x), fx = slab_pair(px ? a.y : a.x, t.inv_d.x, t.oid.x);
-    v2f ny = slab_pair(py ? a.z : a.w, t.inv_d.y, t.oid.y), fy = slab_pair(py ? a.w : a.z, t.inv_d.y, t.oid.y);
-    uint4 b = {0u, 0u, 0u, 0u};
-    if (fmaxf(fmaxf(nx.x, ny.x), tmin) <= fminf(fminf(fx.x, fy.x), limit) || fmaxf(fmaxf(nx.y, ny.y), tmin) <= fminf(fminf(fx.y, fy.y), limit)) {
-        b = n[1];
-    } else {
-        trav_pop<LDS_ENTRIES>(t, stack, deep);
-        return;
-    }
-    v2f nz = slab_pair(pz ? b.x : b.y, t.inv_d.z, t.oid.z), fz = slab_pair(pz ? b.y : b.x, t.inv_d.z, t.oid.z);
-#else
-    uint4 a = n[0], b = n[1];
+    uint4 a, b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (TOP_BYTES && t.cur < TOP_BYTES) {
+        const lds_u4 *l = (const lds_u4 *)(top_lds + t.cur);
+        a = l[0]; b = l[1];
+    } else
+#endif
+    { a = n[0]; b = n[1]; }
     // (left, right) entry and exit distances per axis; a NaN (inf - inf) is dropped by max3/min3
     v2f nx = slab_pair(px ? a.x : a.y, t.inv_d.x, t.oid.x), fx = slab_pair(px ? a.y : a.x, t.inv_d.x, t.oid.x);
     v2f ny = slab_pair(py ? a.z : a.w, t.inv_d.y, t.oid.y), fy = slab_pair(py ? a.w : a.z, t.inv_d.y, t.oid.y);
     v2f nz = slab_pair(pz ? b.x : b.y, t.inv_d.z, t.oid.z), fz = slab_pair(pz ? b.y : b.x, t.inv_d.z, t.oid.z);
-#endif
     float tl = fmaxf(fmaxf(nx.x, ny.x), fmaxf(nz.x, tmin)), tr = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, tmin));
     float el = fminf(fminf(fx.x, fy.x), min_raw(fz.x, limit)), er = fminf(fminf(fx.y, fy.y), min_raw(fz.y, limit));
     bool hl = tl <= el, hr = tr <= er;
@@ -992,15 +986,15 @@ RT_DEV void trav_node16(const uint4 *nodes16, Trav &t, float tmin, uint32_t *sta
     // +inf .. -inf, and with the near and far planes picked by the ray's signs no ray enters it)
     if (hl && hr) {
         bool left_first = tl <= tr;
-        stack_put<LDS_ENTRIES>(deep, t.sp, left_first ? rref : lref);
-        t.sp += RT_STACK_STEP;
+        stack_put<LDS_ENTRIES, STEP>(deep, t.sp, left_first ? rref : lref);
+        t.sp += STEP;
         t.cur = left_first ? lref : rref;
     } else if (hl) {
         t.cur = lref;
     } else if (hr) {
         t.cur = rref;
     } else {
-        trav_pop<LDS_ENTRIES>(t, stack, deep);
+        trav_pop<LDS_ENTRIES, STEP>(t, stack, deep);
     }
 }
 

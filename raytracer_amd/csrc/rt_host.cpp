@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -367,6 +369,7 @@ struct Builder {
     std::vector<BuildItem> items;
     std::vector<float> nodes;      // 16 floats per node
     std::atomic<uint32_t> max_depth{0};
+    std::atomic<bool> failed{false};   // a helper thread of the build ended with an exception
     size_t sweep_below = 0;        // ranges of at most this many items are split by an exact sweep instead of bins
     bool sah = false;
     uint32_t depth_limit = RT_STACK_DEPTH;   // small scenes are kept within 16 levels: the 16-entry-stack kernel holds more waves
@@ -483,10 +486,59 @@ struct Builder {
         while (d > seen && !max_depth.compare_exchange_weak(seen, d, std::memory_order_relaxed)) {}
     }
 
+    // Moves the `top_n` nodes with the largest boxes to the head of the array (the root stays node 0), the others keeping
+    // their pre-order among themselves.  A child's box lies inside its parent's, so the nodes picked form the top of the
+    // tree; a ray visits a node about as often as its box is large, so these are the nodes most often read - the render
+    // kernel of a deep tree keeps them in LDS.  Only the numbering changes: every reference is rewritten, the tree and
+    // its boxes are the same.
+    void hoist_top(size_t top_n) {
+        const size_t n = nodes.size() / 16;
+        if (n < 2 || top_n < 2) return;
+        auto child = [&](size_t node, int k) { uint32_t r; memcpy(&r, nodes.data() + 16 * node + 12 + k, 4); return r; };
+        auto child_area = [&](size_t node, int k) {
+            const float *b = nodes.data() + 16 * node + 6 * k;
+            Box3 box;
+            for (int a = 0; a < 3; a++) { box.mn[a] = b[2 * a]; box.mx[a] = b[2 * a + 1]; }
+            return half_area(box);
+        };
+        std::vector<uint32_t> new_index(n, UINT32_MAX);
+        std::vector<std::pair<float, uint32_t>> heap;          // (area, old index): largest area first, ties by lower index
+        auto less = [](const std::pair<float, uint32_t> &a, const std::pair<float, uint32_t> &b) {
+            return a.first < b.first || (a.first == b.first && a.second > b.second);
+        };
+        heap.push_back({3.4e38f, 0u});
+        uint32_t next = 0;
+        while (!heap.empty() && next < top_n) {
+            std::pop_heap(heap.begin(), heap.end(), less);
+            const uint32_t node = heap.back().second;
+            heap.pop_back();
+            new_index[node] = next++;
+            for (int k = 0; k < 2; k++) {
+                const uint32_t r = child(node, k);
+                if (!(r & RT_REF_LEAF)) { heap.push_back({child_area(node, k), r}); std::push_heap(heap.begin(), heap.end(), less); }
+            }
+        }
+        for (size_t i = 0; i < n; i++)
+            if (new_index[i] == UINT32_MAX) new_index[i] = next++;
+        std::vector<float> moved(nodes.size());
+        for (size_t i = 0; i < n; i++) {
+            float *dst = moved.data() + 16 * (size_t)new_index[i];
+            memcpy(dst, nodes.data() + 16 * i, 64);
+            for (int k = 0; k < 2; k++) {
+                uint32_t r;
+                memcpy(&r, dst + 12 + k, 4);
+                if (!(r & RT_REF_LEAF)) { r = new_index[r]; memcpy(dst + 12 + k, &r, 4); }
+            }
+        }
+        nodes.swap(moved);
+    }
+
     // Builds the whole tree; returns the root's reference.
     uint32_t build_all(Box3 &box) {
         nodes.assign(16 * (items.size() - 1), 0.f);
-        return build(0, items.size(), box, 0, 0);
+        const uint32_t root = build(0, items.size(), box, 0, 0);
+        if (failed.load()) throw std::runtime_error("a tree-building thread failed");
+        return root;
     }
 
     // Builds the subtree over items[lo, hi) with its root at node `idx`; returns its reference and box.
@@ -510,14 +562,24 @@ struct Builder {
         Box3 lb, rb;
         uint32_t l, r;
         const uint32_t left_idx = idx + 1, right_idx = idx + (uint32_t)(mid - lo);
-        std::thread other;
+        // The helper thread is joined on every way out of this scope (an exception on this thread included), and an
+        // exception inside it (std::bad_alloc from a split's vectors) is recorded in `failed` instead of ending the
+        // process: build_all() turns the flag into an exception on the calling thread once every thread has ended.
+        struct Joiner {
+            std::thread t;
+            ~Joiner() { if (t.joinable()) t.join(); }
+        } other;
         if (depth < PAR_LEVELS && hi - lo >= PAR_MIN_ITEMS) {
             // a process that may start no more threads builds this range on the one it has
-            try { other = std::thread([&] { l = build(lo, mid, lb, depth + 1, left_idx); }); } catch (const std::system_error &) {}
+            try {
+                other.t = std::thread([&] {
+                    try { l = build(lo, mid, lb, depth + 1, left_idx); } catch (...) { failed.store(true, std::memory_order_relaxed); }
+                });
+            } catch (const std::system_error &) {}
         }
-        if (!other.joinable()) l = build(lo, mid, lb, depth + 1, left_idx);
+        if (!other.t.joinable()) l = build(lo, mid, lb, depth + 1, left_idx);
         r = build(mid, hi, rb, depth + 1, right_idx);
-        if (other.joinable()) other.join();
+        if (other.t.joinable()) other.t.join();
         float *n = nodes.data() + 16 * (size_t)idx;
         put_box(n, lb);
         put_box(n + 6, rb);
@@ -959,7 +1021,21 @@ int rt_add_sphere_objects(RtScene *sc, int n, const float *center_radius, const 
     return first;
 }
 
+static int scene_commit(RtScene *sc);
+
+// No exception crosses the C boundary: running out of host memory while flattening or building the tree (on this
+// thread or on one of the build's helper threads) comes back as an error code like everything else.
 int rt_scene_commit(RtScene *sc) {
+    try {
+        return scene_commit(sc);
+    } catch (const std::bad_alloc &) {
+        return fail(RT_ERR_LIMIT, "out of host memory while committing the scene");
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_STATE, (std::string("scene commit failed: ") + e.what()).c_str());
+    }
+}
+
+static int scene_commit(RtScene *sc) {
     if (!sc) return fail(RT_ERR_INVALID, "null scene");
     if (sc->committed) return fail(RT_ERR_STATE, "scene already committed");
     if (!sc->ctx) return fail(RT_ERR_STATE, "scene was created without a device context");
@@ -1155,6 +1231,9 @@ int rt_scene_commit(RtScene *sc) {
     } else if (bld.items.size() > 1) {
         Box3 all;
         root = bld.build_all(all);
+        // a tree deeper than the 16 stack entries the spheres kernel keeps per lane is walked by the kernel that holds the
+        // head of the node array in LDS
+        if (bld.max_depth > 16) bld.hoist_top(RT_TOP_NODES_MAX);
     }
     if (bld.max_depth > RT_STACK_DEPTH) return fail(RT_ERR_LIMIT, "BVH deeper than the traversal stack");
 

@@ -17,6 +17,9 @@
 //
 // Both draw sample s of pixel (x, y) from the same generator stream, so they are the same
 // estimator sample for sample.
+#include <atomic>
+#include <cstdlib>
+
 #include "rt_device.h"
 #include "rt_launch.h"
 
@@ -541,6 +544,25 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_accumulate(const float4 *sample
     accum[3 * (size_t)p + 2] += b;
 }
 
+// Diagnostic build only: the arithmetic of one object test priced with the constants the roofline uses
+// (sphere 30, cylinder 95, cuboid 75, quad 45, 6 per merged CSG event - two events per leaf -, 20 per volume
+// interval), so that the phase counters give the flops a kernel executes on scenes of any kind of object.
+RT_DEV uint32_t prim_flops(uint32_t ref) {
+    const uint32_t kind = (ref >> RT_KIND_SHIFT) & 7u;
+    return kind == RT_KIND_SPHERE ? 30u : (kind == RT_KIND_CYLINDER ? 95u : (kind == RT_KIND_CUBOID ? 75u : 45u));
+}
+RT_DEV uint32_t object_flops(const RtDevScene &s, uint32_t ref) {
+    uint32_t kind = (ref >> RT_KIND_SHIFT) & 7u, idx = ref & RT_INDEX_MASK, f = 0;
+    if (kind == RT_KIND_MOTION) { ref = s.motion[idx].base; kind = (ref >> RT_KIND_SHIFT) & 7u; idx = ref & RT_INDEX_MASK; f += 33u; }
+    if (kind == RT_KIND_CDV) { ref = s.cdv[idx].base; kind = (ref >> RT_KIND_SHIFT) & 7u; idx = ref & RT_INDEX_MASK; f += 20u; }
+    if (kind != RT_KIND_CSG) return f + prim_flops(ref);
+    const RtDevCsg &c = s.csg[idx];
+    const uint32_t n = c.n_leaves;
+    const uint32_t *leaves = n > RT_CSG_LEAVES ? s.csg_pool + c.leaf[0] + RT_CSG_POOL_HEADER : c.leaf;
+    for (uint32_t i = 0; i < n; i++) f += prim_flops(leaves[i]) + 12u;
+    return f;
+}
+
 // ------------------------------------------------------------------ fused persistent kernel
 // Lanes whose traversal has ended wait until at least `refill` (default 48) lanes are finished or free, then the
 // wave leaves the traversal loop, shades them (which usually starts their next bounce) and
@@ -573,18 +595,30 @@ __global__ void k_fused_setup(uint32_t *workspace, RtDevCamera cam) {
 // LIST: the scene is small enough to carry its objects as a plain list (RtDevScene::object_list);
 // the extend phase then tests object 0, 1, 2 ... in turn, the same object in every lane: no tree, no
 // stack, no divergence between kinds of object, and every lane with a path takes part.
-template <int FEAT, bool PROF, int STACK, int WPS, bool NODE16, bool DEEP = false, bool LIST = false>
-__global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtDevCamera *camp, uint32_t background, RtDevRender rc, float *accum,
+// BLOCK: threads per workgroup.  TOP: nodes at the head of the 32-byte node array that every workgroup also keeps in
+// LDS (the builder of a deep tree puts the nodes with the largest boxes there); a larger workgroup shares one copy
+// among more waves.
+template <int FEAT, bool PROF, int STACK, int WPS, bool NODE16, bool DEEP = false, bool LIST = false, int BLOCK = RT_BLOCK, int TOP = 0>
+__global__ __launch_bounds__(BLOCK, WPS) void k_fused(RtDevScene s, const RtDevCamera *camp, uint32_t background, RtDevRender rc, float *accum,
                                                      uint32_t *counter, uint32_t n_items, uint32_t tiles_x,
                                                      uint32_t n_tiles, uint32_t chunk_spp, uint32_t knobs, uint32_t heavy_and_counters) {
-    __shared__ uint32_t stack_mem[STACK * RT_BLOCK];
+    __shared__ uint32_t stack_mem[STACK * BLOCK];
     constexpr int LDS_ENTRIES = DEEP ? STACK : 0;
+    constexpr uint32_t STEP = (uint32_t)BLOCK * 4u;       // bytes between a lane's consecutive stack entries
     DeepStack deep_cols;
-    deep_cols.column = (global_u32 *)(uintptr_t)(counter + RT_FUSED_DEEP_OFFSET / 4u) + blockIdx.x * RT_BLOCK + threadIdx.x;
-    deep_cols.stride = gridDim.x * RT_BLOCK;
-    deep_cols.lds_limit = lds_address(stack_mem) + (uint32_t)LDS_ENTRIES * RT_STACK_STEP;
+    deep_cols.column = (global_u32 *)(uintptr_t)(counter + RT_FUSED_DEEP_OFFSET / 4u) + blockIdx.x * BLOCK + threadIdx.x;
+    deep_cols.stride = gridDim.x * BLOCK;
+    deep_cols.lds_limit = lds_address(stack_mem) + (uint32_t)LDS_ENTRIES * STEP;
     const DeepStack *deep = DEEP ? &deep_cols : nullptr;
-    __shared__ float tile_acc[RT_WAVES][192];
+    __shared__ float tile_acc[BLOCK / 64][192];
+    __shared__ __attribute__((aligned(16))) uint4 top_nodes[TOP ? 2 * TOP : 1];
+    uint32_t top_lds = 0;
+    if (TOP) {
+        const uint32_t n_top = min((uint32_t)TOP, s.n_nodes) * 2u;
+        for (uint32_t i = threadIdx.x; i < 2u * TOP; i += BLOCK) top_nodes[i] = i < n_top ? ((const uint4 *)s.nodes16)[i] : make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        top_lds = lds_address((const uint32_t *)top_nodes);
+    }
     constexpr bool SIMPLE = !(FEAT & RT_FEAT_XPRIM);
     const uint32_t refill = knobs & 255u, node_min = (knobs >> 8) & 255u;
     // Ray generation with a defocus disk (a rejection loop) costs about as much as six node steps:
@@ -598,10 +632,12 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
     const uint64_t seed = ((uint64_t)rc.seed_hi << 32) | rc.seed_lo;
     const float4 *nodes = (const float4 *)s.nodes;
     const uint4 *nodes16 = (const uint4 *)s.nodes16;
-    unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // {execs, lanes, cycles} x {shade, raygen, node, leaf}
+    unsigned long long pc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // {execs, lanes, cycles} x {shade, raygen, node, leaf}, flops of the object tests, box tests of the list form
     unsigned long long stamp = 0;
 #define RT_PROF_BEGIN() do { if (PROF) stamp = __builtin_amdgcn_s_memtime(); } while (0)
 #define RT_PROF_END(k, cond) do { if (PROF) { unsigned long long m_ = __ballot(cond); if (m_) { pc[3 * (k)] += 1; pc[3 * (k) + 1] += __popcll(m_); pc[3 * (k) + 2] += __builtin_amdgcn_s_memtime() - stamp; } } } while (0)
+    // adds a per-lane count over the lanes for which `cond` holds (the wave's total goes to lane 0's counter)
+#define RT_PROF_SUM(k, cond, value) do { if (PROF) { uint32_t v_ = (cond) ? (value) : 0u; for (int o_ = 32; o_ > 0; o_ >>= 1) v_ += __shfl_xor(v_, o_); pc[k] += v_; } } while (0)
     // Work items (an 8x8 tile x a chunk of samples) are streamed: when the current item has
     // handed out its last sample the wave takes the next one at once and the free lanes go on
     // with it, while the lanes still walking paths of earlier items finish those on the side.
@@ -755,8 +791,10 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
                     v2f tz = {fmaf(z0, t.inv_d.z, t.oid.z), fmaf(z1, t.inv_d.z, t.oid.z)};
                     bool in_box;
                     (void)box_entry(tx, ty, tz, RT_T_MIN, t.best.t, in_box);
+                    RT_PROF_SUM(13, walking, 1u);
                     wanted = wanted && in_box;
                 }
+                RT_PROF_SUM(12, wanted, object_flops(s, ref));
                 if (wanted)
                     test_object<SIMPLE, (FEAT & RT_FEAT_MOTION) != 0, (FEAT & RT_FEAT_TEXTURE) != 0, true>(s, ref, t.o, t.d, RT_T_MIN, RT_INF, key, nullptr, 0, t.found, t.best, time);
             }
@@ -784,8 +822,8 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
                 if ((n_inner < node_min && n_ready) || n_ready >= leaf_max) break;
                 RT_PROF_BEGIN();
                 if (inner) {
-                    if (NODE16) trav_node16<LDS_ENTRIES>(nodes16, t, RT_T_MIN, stack, deep);
-                    else trav_node<LDS_ENTRIES>(nodes, t, RT_T_MIN, stack, deep);
+                    if (NODE16) trav_node16<LDS_ENTRIES, STEP, TOP * 32u>(nodes16, t, RT_T_MIN, stack, deep, top_lds);
+                    else trav_node<LDS_ENTRIES, STEP>(nodes, t, RT_T_MIN, stack, deep);
                 }
                 RT_PROF_END(2, inner);
                 if (n_inner >= RT_DOUBLE_STEP) {
@@ -793,8 +831,8 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
                     RT_PROF_BEGIN();
                     const bool inner2 = !(t.cur & RT_REF_LEAF);
                     if (inner2) {
-                        if (NODE16) trav_node16<LDS_ENTRIES>(nodes16, t, RT_T_MIN, stack, deep);
-                        else trav_node<LDS_ENTRIES>(nodes, t, RT_T_MIN, stack, deep);
+                        if (NODE16) trav_node16<LDS_ENTRIES, STEP, TOP * 32u>(nodes16, t, RT_T_MIN, stack, deep, top_lds);
+                        else trav_node<LDS_ENTRIES, STEP>(nodes, t, RT_T_MIN, stack, deep);
                     }
                     RT_PROF_END(2, inner2);
                 }
@@ -810,9 +848,10 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
                     if (others) at_leaf = at_leaf && !heavy;
                 }
             }
+            RT_PROF_SUM(12, at_leaf, object_flops(s, t.cur & ~RT_REF_LEAF));
             if (at_leaf) {
                 test_object<SIMPLE, (FEAT & RT_FEAT_MOTION) != 0, (FEAT & RT_FEAT_TEXTURE) != 0, false, (FEAT & RT_FEAT_WIDE_CSG) != 0>(s, t.cur & ~RT_REF_LEAF, t.o, t.d, RT_T_MIN, RT_INF, key, nullptr, 0, t.found, t.best, time);
-                trav_pop<LDS_ENTRIES>(t, stack, deep);
+                trav_pop<LDS_ENTRIES, STEP>(t, stack, deep);
             }
             RT_PROF_END(3, at_leaf);
             uint32_t n_active = (uint32_t)__popcll(__ballot(t.cur != RT_REF_NONE));
@@ -821,10 +860,11 @@ __global__ __launch_bounds__(RT_BLOCK, WPS) void k_fused(RtDevScene s, const RtD
     }
     if (PROF && lane == 0) {
         unsigned long long *out = (unsigned long long *)(counter + RT_FUSED_DIAG_OFFSET / 4u);
-        for (int k = 0; k < 12; k++) atomicAdd(out + k, pc[k]);
+        for (int k = 0; k < 14; k++) atomicAdd(out + k, pc[k]);
     }
 #undef RT_PROF_BEGIN
 #undef RT_PROF_END
+#undef RT_PROF_SUM
 }
 
 // ------------------------------------------------------------------ launchers
@@ -992,7 +1032,7 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
     return hipSuccess;
 }
 
-template <int FEAT, int STACK, int WPS, bool NODE16, bool DEEP = false, bool LIST = false>
+template <int FEAT, int STACK, int WPS, bool NODE16, bool DEEP = false, bool LIST = false, int BLOCK = RT_BLOCK, int TOP = 0>
 static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, const RtDevRender &rc, float *accum,
                                uint32_t *counter, uint32_t knobs, uint32_t knobs2, hipStream_t stream, RtKernelTimer *timer, int cus,
                                bool prepare_only) {
@@ -1003,16 +1043,19 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     if (n_tiles == 0 && !prepare_only) return hipSuccess;
     // workgroups per compute unit of this instantiation: asked once per device (at commit, so
     // that a render call makes no runtime query)
-    static int occ_of_device[64];
+    // (host threads may commit or render at the same time: the table is atomic, and two threads that both find it
+    // empty store the same answer.  The diagnostic build shares the entry of the plain one; it may hold fewer
+    // workgroups per CU, which only means some of the grid waits its turn - workgroups do not depend on one another.)
+    static std::atomic<int> occ_of_device[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    int occ = (dev >= 0 && dev < 64) ? occ_of_device[dev] : 0;
+    int occ = (dev >= 0 && dev < 64) ? occ_of_device[dev].load(std::memory_order_relaxed) : 0;
     if (occ < 1) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS, NODE16, DEEP, LIST>, RT_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
-        if (dev >= 0 && dev < 64) occ_of_device[dev] = occ;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS, NODE16, DEEP, LIST, BLOCK, TOP>, BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
+        if (dev >= 0 && dev < 64) occ_of_device[dev].store(occ, std::memory_order_relaxed);
     }
     if (prepare_only) return hipSuccess;
-    if (DEEP) occ = std::min(occ, 8);        // the deep-stack columns are sized for 8 workgroups per CU
+    if (DEEP) occ = std::min(occ, 2048 / BLOCK);        // the deep-stack columns are sized for 2048 threads per CU
     int grid = cus * occ;
     // Work items = tiles x sample chunks.  Large chunks leave the waves finishing at different
     // times at the end of the launch (with 3 chunks per tile that tail was 15 % of a 1024-spp
@@ -1020,13 +1063,14 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     // item into the next: chunks of about 32 samples per pixel, more of them while that gives
     // fewer than 96 items per resident wave, never below 4 samples per pixel.
     const uint32_t target = 32u, min_chunk = 4u;
-    uint32_t want_items = (uint32_t)grid * RT_WAVES * 96u;
+    constexpr uint32_t WAVES = BLOCK / 64;
+    uint32_t want_items = (uint32_t)grid * WAVES * 96u;
     uint32_t n_chunks = std::max((rc.spp + target / 2u) / target, (want_items + n_tiles - 1u) / n_tiles);
     n_chunks = std::max(1u, std::min(n_chunks, std::max(1u, rc.spp / min_chunk)));
     uint32_t chunk_spp = (rc.spp + n_chunks - 1u) / n_chunks;
     n_chunks = (rc.spp + chunk_spp - 1u) / chunk_spp;
     uint32_t n_items = n_tiles * n_chunks;
-    grid = (int)std::min<uint32_t>((uint32_t)grid, (n_items + RT_WAVES - 1u) / RT_WAVES);
+    grid = (int)std::min<uint32_t>((uint32_t)grid, (n_items + WAVES - 1u) / WAVES);
     // item counters: as many as there are workgroups to serve them, at most RT_ITEM_COUNTERS, a power of two
     uint32_t counters_log2 = 0;
     while ((2u << counters_log2) <= RT_ITEM_COUNTERS && (16u << counters_log2) <= (uint32_t)grid) counters_log2++;
@@ -1037,9 +1081,9 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     const RtDevCamera *camp = (const RtDevCamera *)((const char *)counter + RT_FUSED_CAMERA_OFFSET);
     if (timer) timer->begin(stream);
     if (prof)
-        k_fused<FEAT, true, STACK, WPS, NODE16, DEEP, LIST><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u) | (counters_log2 << 8));
+        k_fused<FEAT, true, STACK, WPS, NODE16, DEEP, LIST, BLOCK, TOP><<<grid, BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u) | (counters_log2 << 8));
     else
-        k_fused<FEAT, false, STACK, WPS, NODE16, DEEP, LIST><<<grid, RT_BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u) | (counters_log2 << 8));
+        k_fused<FEAT, false, STACK, WPS, NODE16, DEEP, LIST, BLOCK, TOP><<<grid, BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u) | (counters_log2 << 8));
     if (timer) timer->end(stream);
     return hipGetLastError();
 }
@@ -1078,6 +1122,14 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
         if (bvh_depth <= 16) return RT_FUSED(0, 16, RT_WPS0);
         // a deep tree (a million spheres) waits on memory, not on the ALUs: 8 waves per SIMD with
         // the rare deep stack entries in global memory beat 5 waves with the whole stack in LDS
+        if (n16 && (workspace_bytes >= rt_fused_workspace_bytes(cus) || prepare_only)) {
+            // experiment switch: the top of the tree in LDS, shared by a larger workgroup
+            static const int variant = getenv("RT_DEEP_VARIANT") ? atoi(getenv("RT_DEEP_VARIANT")) : 0;
+            if (variant == 1) return fused_launch<0, 16, 6, true, true, false, 512, 448>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
+            if (variant == 2) return fused_launch<0, 16, 7, true, true, false, 896, 416>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
+            if (variant == 3) return fused_launch<0, 12, 7, true, true, false, 896, 832>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
+            if (variant == 4) return fused_launch<0, 16, 6, true, true, false, 512, 0>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
+        }
         if (workspace_bytes >= rt_fused_workspace_bytes(cus) || prepare_only) {
             hipError_t e = n16 ? fused_launch<0, 16, RT_WPS_DEEP, true, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only)
                                : fused_launch<0, 16, RT_WPS_DEEP, false, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
@@ -1105,23 +1157,24 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
 // current (rt_static_scratch_init), and only that pointer is handed to kernels and memsets.
 #define RT_STATIC_SCRATCH_BYTES (RT_FUSED_DEEP_OFFSET + (size_t)RT_STATIC_MAX_CUS * 8u * RT_BLOCK * (RT_STACK_DEPTH - 16) * 4u)
 static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
-static void *scratch_of_device[RT_STATIC_MAX_DEVICES];
+static std::atomic<void *> scratch_of_device[RT_STATIC_MAX_DEVICES];     // contexts may be created from several host threads
 
 hipError_t rt_static_scratch_init(int device) {
     if (device < 0 || device >= RT_STATIC_MAX_DEVICES) return hipErrorInvalidDevice;
-    if (scratch_of_device[device]) return hipSuccess;
+    if (scratch_of_device[device].load(std::memory_order_acquire)) return hipSuccess;
     void *ptr = nullptr;
     hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
     if (e != hipSuccess) return e;
     if (!ptr) return hipErrorInvalidSymbol;
-    scratch_of_device[device] = ptr;
+    scratch_of_device[device].store(ptr, std::memory_order_release);      // every thread resolves the same address
     return hipSuccess;
 }
 
 hipError_t rt_render_fused_static(const RtDevScene &s, uint32_t feat, uint32_t bvh_depth, const RtDevCamera &cam, RtDevRender rc,
                                   uint32_t knobs, float *accum, hipStream_t stream, int cus, int device, uint32_t knobs2) {
-    if (device < 0 || device >= RT_STATIC_MAX_DEVICES || !scratch_of_device[device]) return hipErrorNotInitialized;
+    void *ptr = (device >= 0 && device < RT_STATIC_MAX_DEVICES) ? scratch_of_device[device].load(std::memory_order_acquire) : nullptr;
+    if (!ptr) return hipErrorNotInitialized;
     // a device with more compute units than the columns were sized for runs the grid of RT_STATIC_MAX_CUS units
-    return rt_render_fused(s, feat, bvh_depth, cam, rc, knobs, accum, scratch_of_device[device], RT_STATIC_SCRATCH_BYTES, stream,
+    return rt_render_fused(s, feat, bvh_depth, cam, rc, knobs, accum, ptr, RT_STATIC_SCRATCH_BYTES, stream,
                            nullptr, std::min(cus, RT_STATIC_MAX_CUS), false, knobs2);
 }

@@ -40,6 +40,7 @@ enum RtPrimKind : uint32_t {
 // the fused workspace all follow this one definition.
 #define RT_STACK_DEPTH 24
 #define RT_BLOCK 256             // threads per workgroup of every traversal kernel
+#define RT_TOP_NODES_MAX 1024    // nodes the builder of a deep tree moves to the head of the node array, largest boxes first
 #define RT_LINEAR_MAX 16         // scenes up to this many objects are rendered without a tree
 #define RT_CSG_LEAVES 8           // leaves whose intervals the walk over a CSG shape keeps in registers
 #define RT_CSG_WIDE_LEAVES 64     // leaves of a shape that is walked by recomputing intervals (RT_CSG_MAX_LEAVES of the C ABI)

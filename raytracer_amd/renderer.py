@@ -219,6 +219,12 @@ class Renderer:
             scene.encode(self.native, dedup=dedup)
             self.native.set_option(abi.RT_OPTION_BVH_BUILDER, bvh)
             self.native.set_option(abi.RT_OPTION_NODE_FORMAT, nodes)
+        if native is not None and (refill or node_min is not None or heavy_min is not None or traversal is not None
+                                   or timing or profile_phases):
+            # these are properties of the committed scene, shared by every renderer on it: setting them here would
+            # silently change the kernels of the others
+            raise ValueError("refill / node_min / heavy_min / traversal / timing / profile_phases belong to the scene: "
+                             "set them with native.set_option() before sharing it, not per Renderer")
         if refill:
             self.native.set_option(abi.RT_OPTION_REFILL_THRESHOLD, refill)
         if node_min is not None:
@@ -250,7 +256,9 @@ class Renderer:
             # every shard's buffer has the rows of shard 0 (the largest), so that equal-sized buffers can be gathered
             rows = check(lib.rt_band_rows(height, 0, self.bands[1]))
         self.accum = torch.zeros((rows, width, 3), dtype=torch.float32, device=self.ctx.device)
-        ws = lib.rt_render_workspace_size(self.pipeline, width, height)
+        # the size follows the compute-unit count of the current device: ask with the scene's device current
+        with torch.cuda.device(self.ctx.device):
+            ws = lib.rt_render_workspace_size(self.pipeline, width, height)
         self.workspace = torch.empty(max(ws, 256), dtype=torch.uint8, device=self.ctx.device)
         self.pass_counter = 0
         self.samples = 0

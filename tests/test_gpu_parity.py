@@ -1,13 +1,14 @@
 """Parity of the HIP path against the CPU oracle, through the C ABI (GPU needed).
 
 Bars (stated per test):
-  * known-answer vectors of the reference's own tests: 2^-17 absolute, the bar the
-    float build of the oracle is held to (the reference's 2^-20 assumes its compiler's
-    exact contraction pattern);
+  * known-answer vectors of the reference's own tests: 2^-20 absolute, the reference's own
+    bar (MetalRayTracerTests/Utils.swift:9-13), in every case (measured on MI355X: the rotated
+    cylinder and the fog scatter land within 2^-20, the transformed box within 2^-21, every other
+    case within 2^-22 or better);
   * first hit vs the double-precision oracle: object, material and face identical; t
     within 1e-5 * |t| and normals within 5e-5 on hits of objects that do not dwarf their
     distance (compare_first_hits asserts the fraction that meets this, per scene); on a
-    1000-unit ground sphere seen from 10 units the bound is 1e-5 of the object's reach,
+    1000-unit ground sphere seen from 10 units the bound is 6e-6 of the object's reach (3.7e-6 measured),
     the float32 floor (the centre alone carries 6e-5 of rounding).  Grazing hits (normal
     perpendicular to the ray to 0.2 degrees) are ill-conditioned in t and in the side the
     normal is flipped to; they are counted and bounded.
@@ -48,7 +49,8 @@ def test_reference_known_answers(ctx, case):
     ray = np.array([case["ray"][0] + case["ray"][1]], dtype=np.float32)
     events = [_Ev(e) for e in sink.intervals(sid, ray, scripted=case["rng"])[0]]
     exp = case["hits"]
-    tol = FIX["tolerance"] * 8
+    tol = FIX["tolerance"]
+    assert tol == 2.0 ** -20
     if case.get("first_only"):
         assert len(events) >= 1
         check_event(events[0], exp[0], tol, case["name"])
@@ -96,7 +98,7 @@ def classify_first_hits(gpu, ref, rays, scene):
 
 
 def compare_first_hits(gpu, ref, rays, scene, what="", rel=1e-5, normal_tol=5e-5, strict_frac=0.999, max_bad_frac=1e-3,
-                       max_grazing_frac=5e-3):
+                       max_grazing_frac=5e-3, rel_reach=6e-6):
     """The bar of the first-hit comparison, asserted (not printed):
       * object identical on all but max_bad_frac of the rays (an exact tie between two objects, or
         a silhouette where one precision hits and the other misses);
@@ -104,8 +106,8 @@ def compare_first_hits(gpu, ref, rays, scene, what="", rel=1e-5, normal_tol=5e-5
         material and face identical, |dt| <= 1e-5 * |t| AND normals within 5e-5 (measured on
         MI355X over every scene of the tests: all of them, largest |dt| / |t| 4.1e-6, largest normal
         difference 4.3e-5);
-      * on hits on big objects: the same with |dt| <= 1e-5 * reach (measured: at most 3.7e-6 * reach,
-        at the horizon of the 1000-unit ground sphere);
+      * on hits on big objects: the same with |dt| <= 6e-6 * reach (measured: at most 3.7e-6 * reach,
+        at the horizon of the 1000-unit ground sphere; the bar is that plus a margin);
       * grazing hits: object only; there may be at most max_grazing_frac of them."""
     c = classify_first_hits(gpu, ref, rays, scene)
     n = len(rays)
@@ -113,7 +115,7 @@ def compare_first_hits(gpu, ref, rays, scene, what="", rel=1e-5, normal_tol=5e-5
     plain = hit & ~grazing & ~big
     large = hit & ~grazing & big
     ok_plain = (c["dt"] <= rel * np.maximum(c["t_ref"], 1e-3)) & (c["dn"] <= normal_tol) & c["ids"]
-    ok_large = (c["dt"] <= rel * c["reach"]) & (c["dn"] <= normal_tol) & c["ids"]
+    ok_large = (c["dt"] <= rel_reach * c["reach"]) & (c["dn"] <= normal_tol) & c["ids"]
     info = dict(n=n, hits=int(hit.sum()), object_mismatch=int((~c["same_obj"]).sum()),
                 plain=int(plain.sum()), plain_strict_frac=float(ok_plain[plain].mean()) if plain.any() else 1.0,
                 plain_max_dt_rel=float((c["dt"][plain] / np.maximum(c["t_ref"][plain], 1e-3)).max()) if plain.any() else 0.0,
@@ -123,7 +125,8 @@ def compare_first_hits(gpu, ref, rays, scene, what="", rel=1e-5, normal_tol=5e-5
                 large=int(large.sum()), large_ok_frac=float(ok_large[large].mean()) if large.any() else 1.0,
                 large_max_dt_over_reach=float((c["dt"][large] / c["reach"][large]).max()) if large.any() else 0.0,
                 grazing=int((hit & grazing).sum()))
-    print(what, info)
+    print(what, "rays per class: plain %d, on big objects %d, grazing %d, misses or object mismatches %d;" % (
+        info["plain"], info["large"], info["grazing"], n - info["plain"] - info["large"] - info["grazing"]), info)
     assert info["object_mismatch"] <= max(1, int(max_bad_frac * n)), (what, info)
     assert info["plain_strict_frac"] >= strict_frac, (what, info)
     assert info["large_ok_frac"] >= strict_frac, (what, info)

@@ -78,3 +78,53 @@ def test_static_scratch_render_refuses_oversized_images_and_bad_arguments():
     assert lib.rt_render_static(r.native.h, C.byref(cc), C.byref(rc), 0, 16, 16, acc.data_ptr(), None) == 0
     torch.cuda.synchronize()
     assert acc.sum().item() > 0
+
+
+def test_static_scratch_render_allocates_nothing_and_runs_under_graph_capture():
+    """The callers this entry point is for.  (1) Device memory: the free bytes the runtime reports
+    (hipMemGetInfo) and torch's own allocator are where they were after a call.  (2) Stream capture:
+    two calls (the second on a smaller image) recorded into a HIP graph on a side stream - a call that
+    allocated, synchronised or queried the stream would fail the capture - then replayed twice; every
+    replay adds the same sums rt_render gives."""
+    from raytracer_amd._native import check, lib
+    from raytracer_amd.renderer import Renderer
+    scene = deep_cloud()
+    sizes = [(192, 108), (77, 41)]
+    first = Renderer(scene, *sizes[0])
+    assert first.native.stats()["bvh_depth"] > 16
+    refs, accs = [], []
+    for k, (w, h) in enumerate(sizes):
+        ref = Renderer(scene, w, h, native=first.native)
+        ref.draw(3, 12, 91 + k, first_sample=2)
+        refs.append(ref)
+        accs.append(torch.zeros((h, w, 3), dtype=torch.float32, device=first.ctx.device))
+    torch.cuda.synchronize()
+    # (1) nothing allocated by a plain call
+    warm = render_static(refs[0], *sizes[0], 1, 2, 5)       # torch allocates `warm` here, before the measurement
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    held0 = torch.cuda.memory_allocated()
+    rc = RenderConfig(3, 12, 1, 91, 2).impl
+    cc = refs[0].camera.impl
+    check(lib.rt_render_static(first.native.h, C.byref(cc), C.byref(rc), 2, sizes[0][0], sizes[0][1], warm.data_ptr(),
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0 and torch.cuda.memory_allocated() == held0
+    # (2) capture and replay
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(graph, stream=side):
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for k, (w, h) in enumerate(sizes):
+            rc = RenderConfig(3, 12, 1, 91 + k, 2).impl
+            cc = refs[k].camera.impl
+            check(lib.rt_render_static(first.native.h, C.byref(cc), C.byref(rc), 2, w, h, accs[k].data_ptr(), stream))
+    torch.cuda.synchronize()
+    for replay in (1, 2):
+        graph.replay()
+        torch.cuda.synchronize()
+        for k in range(2):
+            want = refs[k].accum * replay         # the kernel adds to the accumulator it is given
+            scale = max(1.0, want.abs().max().item())
+            assert (accs[k] - want).abs().max().item() <= 1e-5 * scale, (replay, sizes[k])

@@ -28,23 +28,30 @@ _nodes = {"auto": abi.RT_NODES_AUTO, "f32": abi.RT_NODES_F32, "f16": abi.RT_NODE
 r = Renderer(scene, w, h, profile_phases=True, nodes=_nodes, refill=int(_os.environ["RT_REFILL"]) if "RT_REFILL" in _os.environ else None)
 r.draw(spp, depth, seed)
 torch.cuda.synchronize()
-pc = r.workspace[1024:1024 + 96].cpu().numpy().view(np.uint64).reshape(4, 3)
+raw = r.workspace[1024:1024 + 112].cpu().numpy().view(np.uint64)
+pc = raw[:12].reshape(4, 3)
+object_flops, list_boxes = float(raw[12]), float(raw[13])
 tot = pc[:, 2].sum()
 for nm, (ex, ln, cy) in zip(["shade", "raygen", "node", "leaf"], pc):
     print("%-7s execs %12d  lanes/exec %5.1f  cycles/exec %7.1f  cycle share %.3f" % (nm, ex, ln / max(ex, 1), cy / max(ex, 1), cy / tot))
 samples = w * h * spp
 print("samples", samples)
-print("node visits per sample %.2f  leaf tests per sample %.2f" % (pc[2, 1] / samples, pc[3, 1] / samples))
+print("node visits per sample %.2f  leaf tests per sample %.2f  flops of object tests per sample %.1f  list box tests per sample %.2f"
+      % (pc[2, 1] / samples, pc[3, 1] / samples, object_flops / samples, list_boxes / samples))
 st = r.native.stats()
-if len(sys.argv) > 3 and st["n_spheres"] == st["n_objects"]:
-    fixture = os.path.join(ROOT, "tests", "golden", "counters_%s.json" % name)
+fixture = os.path.join(ROOT, "tests", "golden", "counters_%s.json" % name)
+if len(sys.argv) > 3 and os.path.exists(fixture):
     cnt = json.load(open(fixture))["counters"]
     n = float(cnt["samples"])
     shade = (sum(cnt["shades"][k] * f for k, f in roofline.F_SHADE.items()) + cnt["hits"] * roofline.F_HIT) / n
     nodes, leaves = pc[2, 1] / samples, pc[3, 1] / samples
-    executed = roofline.F_RAYGEN + roofline.F_ACCUM + shade + nodes * 2 * roofline.F_BOX + leaves * roofline.F_SPHERE
-    json.dump({"workload": name, "spp": spp, "node_visits_per_sample": nodes, "sphere_tests_per_sample": leaves,
+    executed = (roofline.F_RAYGEN + roofline.F_ACCUM + shade + nodes * 2 * roofline.F_BOX + object_flops / samples
+                + list_boxes / samples * roofline.F_BOX / 2)
+    json.dump({"workload": name, "spp": spp, "node_visits_per_sample": nodes, "object_tests_per_sample": leaves,
+               "object_test_flops_per_sample": object_flops / samples, "list_box_tests_per_sample": list_boxes / samples,
                "shade_flops_per_sample": shade, "executed_flops_per_sample": executed,
                "note": "phase counters of the diagnostic k_fused build (tools/phase_profile.py): lanes that took part in node steps "
-                       "and leaf tests; a node visit is two box tests"}, open(sys.argv[3], "w"), indent=1)
+                       "(a node visit is two box tests) and object tests, each object test priced by the kinds of primitive it "
+                       "computes intervals of (roofline.py constants; a CSG shape: its leaves + two merge events per leaf); "
+                       "shading from the oracle's event counts"}, open(sys.argv[3], "w"), indent=1)
     print("executed flops per sample %.1f" % executed)
