@@ -513,6 +513,82 @@ template <class R> struct CompositionEnum final : Enum<R> {
     void texture_coordinates(R &u, R &v) const override { children[cur]->texture_coordinates(u, v); }
 };
 
+// RayTracingKit/Hittable.swift:394-526: the Kit's Composition.  Where the Metal side merges the events of all children
+// at once and counts depth (CompositionEnum above), the Kit keeps a list of ranges per operand and folds the operands
+// from the left, two lists at a time: enumerateHits (:432-460) walks both lists in order of t - the right-hand list
+// first on a tie - and makeUnion / makeIntersection / makeDifference (:462-526) rebuild ranges from the depth count;
+// a hit of a subtracted operand is `inverted` (:64-68: its side flips).  Used for scenes under the Kit's conventions,
+// so that images of the Kit's worlds are checked against the Kit's own interval algebra.  The events come out in the
+// enumerator protocol of the Metal side (normals as enumerated; the Kit stores a normal already turned against the
+// ray, which is the same normal after HitInfo::set_normal), so the normal of an inverted hit is negated here.
+template <class R> struct KitCompositionEnum final : Enum<R> {
+    struct Ev { R t; bool exit; V3<R> p, n; uint64_t mat; R u, v; };
+    std::vector<Ev> events;          // entry, exit, entry, exit, ... of the result
+    size_t idx = 0;
+
+    static std::vector<Ev> collect(Enum<R> &e) {
+        std::vector<Ev> out;
+        for (; e.hasNext(); e.move()) {
+            Ev v;
+            v.t = e.t(); v.exit = e.isExit();
+            const bool fin = std::isfinite(v.t);          // the open end of a quad's half space has no surface
+            v.p = fin ? e.point() : V3<R>{}; v.n = fin ? e.normal() : V3<R>{};
+            v.mat = fin ? e.material_offset() : 0;
+            v.u = v.v = 0;
+            if (fin) e.texture_coordinates(v.u, v.v);
+            out.push_back(v);
+        }
+        return out;
+    }
+    static Ev inverted(Ev v) { v.exit = !v.exit; v.n = v.n * R(-1); return v; }
+
+    // enumerateHits + the three make... functions; op: 0 union, 1 intersection, 2 difference
+    static std::vector<Ev> fold(const std::vector<Ev> &lhs, const std::vector<Ev> &rhs, int op, Counters *counters) {
+        std::vector<Ev> result;
+        bool has_entry = false;
+        Ev entry{};
+        int depth = 0;
+        size_t i = 0, j = 0;
+        while (i < lhs.size() || j < rhs.size()) {
+            bool is_right;
+            if (i < lhs.size() && j < rhs.size()) is_right = !(lhs[i].t < rhs[j].t);      // :439-445
+            else is_right = i >= lhs.size();
+            const Ev &hit = is_right ? rhs[j++] : lhs[i++];
+            if (counters) counters->csg_events++;
+            const bool front = !hit.exit;
+            if (op == 0) {                                                            // :462-481
+                if (front) { if (!has_entry) { entry = hit; has_entry = true; } depth++; }
+                else { depth--; if (depth == 0) { result.push_back(entry); result.push_back(hit); has_entry = false; } }
+            } else if (op == 1) {                                                     // :483-502
+                if (front) { depth++; if (depth == 2) { entry = hit; has_entry = true; } }
+                else { if (depth == 2) { result.push_back(entry); result.push_back(hit); has_entry = false; } depth--; }
+            } else {                                                                  // :504-526
+                if (front != is_right) depth++; else depth--;
+                if (depth == 1) { entry = is_right ? inverted(hit) : hit; has_entry = true; }
+                else if (has_entry) { result.push_back(entry); result.push_back(is_right ? inverted(hit) : hit); has_entry = false; }
+            }
+        }
+        return result;
+    }
+
+    KitCompositionEnum(const TraceCtx<R> &ctx, const Shape &s, Ray<R> ray, int object) {
+        const int op = s.subtract ? 2 : (s.min_count > 1 ? 1 : 0);
+        for (size_t k = 0; k < s.children.size(); k++) {
+            auto child = make_enum<R>(ctx, s.children[k], ray, object);
+            std::vector<Ev> next = collect(*child);
+            events = k == 0 ? next : fold(events, next, op, ctx.counters);           // :416-430
+        }
+    }
+    bool hasNext() const override { return idx < events.size(); }
+    void move() override { idx++; }
+    bool isExit() const override { return events[idx].exit; }
+    R t() const override { return events[idx].t; }
+    V3<R> point() const override { return events[idx].p; }
+    V3<R> normal() const override { return events[idx].n; }
+    uint64_t material_offset() const override { return events[idx].mat; }
+    void texture_coordinates(R &u, R &v) const override { u = events[idx].u; v = events[idx].v; }
+};
+
 // RenderableImpl.h:727-802.  The reference draws from the path's generator inside
 // traversal and keeps the advance even for candidates that lose, which makes the result
 // depend on the traversal order of an opaque BVH.  Here (and in the HIP path) the draws
@@ -675,7 +751,9 @@ template <class R> std::unique_ptr<Enum<R>> make_enum(const TraceCtx<R> &ctx, in
     case CYLINDER: return std::make_unique<CylinderEnum<R>>(s, ray);
     case CUBOID: return std::make_unique<CuboidEnum<R>>(s, ray);
     case QUAD: return std::make_unique<QuadEnum<R>>(s, ray);
-    case COMPOSITION: return std::make_unique<CompositionEnum<R>>(ctx, s, ray, object);
+    case COMPOSITION:
+        if (ctx.scene->kit_convention) return std::make_unique<KitCompositionEnum<R>>(ctx, s, ray, object);
+        return std::make_unique<CompositionEnum<R>>(ctx, s, ray, object);
     case MOTION: return std::make_unique<MotionEnum<R>>(ctx, s, ray, object);
     default: return std::make_unique<CdvEnum<R>>(ctx, s, ray, object);
     }
@@ -695,10 +773,15 @@ template <class R> struct HitInfo {
 // bound wins for this object.  The upper bound is inclusive for the caller's own tmax
 // (Shaders.metal:188) and exclusive once a closer hit of another object has shrunk it
 // (half-open Range of Hittable.swift:643).
+// A hit is a finite distance.  The two reference renderers part ways here: RayTracingKit's range is
+// 0.001 ..< infinity (Camera.swift:117 with the half-open Range of Hittable.swift:111-122), which no event at
+// +infinity can lie in; Shaders.metal:187-190 compares `distance <= maxDistance` against an infinite maximum and so
+// accepts the open end of a quad's half space (RenderableImpl.h:416-417) for a ray that leaves the quad's back -
+// shading the plane point once more.  The Kit is the renderer the images are judged against, so its rule is kept.
 template <class R, class E> bool first_in_range(E &e, Ray<R> ray, R lo, R hi, bool hi_open, int object, HitInfo<R> &out) {
     for (; e.hasNext(); e.move()) {
         R d = e.t();
-        bool ok = d >= lo && (hi_open ? d < hi : d <= hi);
+        bool ok = d >= lo && (hi_open ? d < hi : d <= hi) && std::isfinite(d);
         if (ok) {
             out.t = d;
             out.point = e.point();
@@ -721,7 +804,9 @@ template <class R> bool hit_object(const TraceCtx<R> &ctx, int object, Ray<R> ra
     case CYLINDER: { CylinderEnum<R> e(s, ray); return first_in_range(e, ray, lo, hi, hi_open, object, out); }
     case CUBOID: { CuboidEnum<R> e(s, ray); return first_in_range(e, ray, lo, hi, hi_open, object, out); }
     case QUAD: { QuadEnum<R> e(s, ray); return first_in_range(e, ray, lo, hi, hi_open, object, out); }
-    case COMPOSITION: { CompositionEnum<R> e(ctx, s, ray, object); return first_in_range(e, ray, lo, hi, hi_open, object, out); }
+    case COMPOSITION:
+        if (ctx.scene->kit_convention) { KitCompositionEnum<R> e(ctx, s, ray, object); return first_in_range(e, ray, lo, hi, hi_open, object, out); }
+        else { CompositionEnum<R> e(ctx, s, ray, object); return first_in_range(e, ray, lo, hi, hi_open, object, out); }
     case MOTION: { MotionEnum<R> e(ctx, s, ray, object); return first_in_range(e, ray, lo, hi, hi_open, object, out); }
     default: { CdvEnum<R> e(ctx, s, ray, object); return first_in_range(e, ray, lo, hi, hi_open, object, out); }
     }

@@ -278,7 +278,11 @@ RT_DEV Span cuboid_span(const XPrim &x, f3 o, f3 d) {
 
 // Impl/RenderableImpl.h:395-436: the quad as the half space behind its plane, cut to
 // the parallelogram.  Record: origin (c0), v x w (c1), w x u (c2), normal (p0..p2), d (p3).
-RT_DEV Span quad_span(const XPrim &x, f3 o, f3 d, float &alpha, float &beta) {
+// plain: the quad stands alone (not an operand of a CSG shape, not the boundary of a volume): the far end of its half
+// space is then no event of its own - a hit is a finite distance, the range of RayTracingKit is 0.001 ..< infinity
+// (Camera.swift:117), where Shaders.metal:187-190 would take t = +inf for a hit and shade the plane point once more for a
+// ray that leaves the quad's back - so both ends of the interval are the plane hit.
+RT_DEV Span quad_span(const XPrim &x, f3 o, f3 d, float &alpha, float &beta, bool plain = false) {
     f3 normal = mk3(x.p0, x.p1, x.p2);
     float denom = dot(d, normal);
     float t = (x.p3 - dot(o, normal)) * rcp(denom);
@@ -290,21 +294,21 @@ RT_DEV Span quad_span(const XPrim &x, f3 o, f3 d, float &alpha, float &beta) {
         beta = dot(x.c2, p);
         if (!(alpha < 0.0f || alpha > 1.0f || beta < 0.0f || beta > 1.0f)) {
             sp.t0 = denom < 0.0f ? t : -RT_INF;
-            sp.t1 = denom < 0.0f ? RT_INF : t;
+            sp.t1 = (denom < 0.0f && !plain) ? RT_INF : t;
         }
     }
     return sp;
 }
 
 template <bool UNI = false>
-RT_DEV Span prim_span(const RtDevScene &s, uint32_t ref, f3 o, f3 d) {
+RT_DEV Span prim_span(const RtDevScene &s, uint32_t ref, f3 o, f3 d, bool plain = false) {
     uint32_t kind = (ref >> RT_KIND_SHIFT) & 7u, idx = ref & RT_INDEX_MASK;
     if (kind == RT_KIND_SPHERE) return sphere_span<UNI>(s, idx, o, d);
     XPrim x = load_xprim<UNI>(s, idx);
     if (kind == RT_KIND_CYLINDER) return cylinder_span(x, o, d);
     if (kind == RT_KIND_CUBOID) return cuboid_span(x, o, d);
     float al, be;
-    return quad_span(x, o, d, al, be);
+    return quad_span(x, o, d, al, be, plain);
 }
 
 // ------------------------------------------------------------------ hit completion
@@ -457,7 +461,7 @@ RT_DEV void csg_begin(const RtDevScene &s, uint32_t shape, f3 o, f3 d, CsgIter &
         for (int i = 0; i < RT_CSG_LEAVES; i++) { it.tin[i] = RT_INF; it.tout[i] = RT_INF; }
     }
     for (uint32_t i = 0; i < n; i++) {
-        Span sp = prim_span<UNI>(s, is_csg ? ld<UNI>(&c->leaf[i]) : shape, o, d);
+        Span sp = prim_span<UNI>(s, is_csg ? ld<UNI>(&c->leaf[i]) : shape, o, d, only_first);
         bool ok = span_valid(sp);
         float a = ok ? sp.t0 : RT_INF, b = ok ? sp.t1 : RT_INF;
         if (only_first) {
@@ -639,8 +643,13 @@ RT_DEV uint32_t code_leaf(uint32_t code) {
 }
 
 // Accept rule of Shaders.metal:182-199 for one candidate distance.
-RT_DEV bool in_range(float t, float tmin, float tmax_incl, bool found, float best) {
-    return t >= tmin && (found ? t < best : t <= tmax_incl);
+// tie_wins: a candidate at exactly the closest distance so far replaces it (set when the object under test comes
+// before the holder of that distance in the order the reference would have met them, RayTracingKit/Hittable.swift:662-671).
+// (A hit is a finite distance - RayTracingKit's range is 0.001 ..< infinity, Camera.swift:117 - and the only infinite
+// interval ends are the open end of a quad's half space and of shapes built from quads: quad_span gives a quad that
+// stands alone a closed interval, CSG walks never reach an end at infinity, the volume code checks its exit.)
+RT_DEV bool in_range(float t, float tmin, float tmax_incl, bool found, float best, bool tie_wins = false) {
+    return t >= tmin && (found ? (t < best || (tie_wins && t == best)) : t <= tmax_incl);
 }
 
 // Constant-density volume over a primitive (one interval [t_in, t_out]), RenderableImpl.h:737-777:
@@ -648,7 +657,7 @@ RT_DEV bool in_range(float t, float tmin, float tmax_incl, bool found, float bes
 template <bool UNI>
 RT_DEV void volume_over_primitive(const RtDevScene &s, uint32_t cdv_idx, uint32_t self, float t_in, float t_out, uint32_t tag_in,
                                   uint32_t tag_out, float neg_inv_density, float tmin, float tmax, uint64_t volume_key,
-                                  const float *scripted, bool &found, Best &best) {
+                                  const float *scripted, bool &found, Best &best, bool tie_wins = false) {
     const float t1 = fmaxf(0.0f, t_in), t2 = t_out;
     if (!(t1 < t2)) return;
     if (found && best.t <= t1) return;      // nothing inside the medium can beat the current hit
@@ -657,8 +666,8 @@ RT_DEV void volume_over_primitive(const RtDevScene &s, uint32_t cdv_idx, uint32_
     else { Pcg vr = pcg_seed(volume_key, (uint64_t)(ld<UNI>(s.cdv_obj + cdv_idx) + 1u)); u = rnd(vr); }
     const float t = fmaf(log_unit(1.0f - u), neg_inv_density, t1);
     if (!(t <= t2)) return;
-    if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = self; best.code = RT_CODE_SCATTER | tag_in; found = true; }
-    else if (in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = self; best.code = tag_out; found = true; }
+    if (in_range(t, tmin, tmax, found, best.t, tie_wins)) { best.t = t; best.ref = self; best.code = RT_CODE_SCATTER | tag_in; found = true; }
+    else if (t2 < RT_INF && in_range(t2, tmin, tmax, found, best.t, tie_wins)) { best.t = t2; best.ref = self; best.code = tag_out; found = true; }
 }
 
 RT_DEV uint32_t event_code(const CsgIter &it) { return it.tag | (it.leaf << 3) | ((it.leaf_exit ? 1u : 0u) << RT_CODE_LEAF_EXIT_SHIFT); }
@@ -669,9 +678,9 @@ RT_DEV uint32_t event_code(const It &it) {
 
 // First boundary of a shape that is an acceptable hit (Shaders.metal:182-199 on the shape's event list).
 template <class It>
-RT_DEV void walk_boundary(const RtDevScene &s, It &it, uint32_t self, float tmin, float tmax, bool &found, Best &best) {
+RT_DEV void walk_boundary(const RtDevScene &s, It &it, uint32_t self, float tmin, float tmax, bool &found, Best &best, bool tie_wins = false) {
     while (csg_next(s, it)) {
-        if (in_range(it.t, tmin, tmax, found, best.t)) {
+        if (in_range(it.t, tmin, tmax, found, best.t, tie_wins)) {
             best.t = it.t; best.ref = self;
             best.code = event_code(it);
             found = true;
@@ -685,7 +694,7 @@ RT_DEV void walk_boundary(const RtDevScene &s, It &it, uint32_t self, float tmin
 // interval of the base shape; a scatter inside the interval is followed by the interval's exit.
 template <class It>
 RT_DEV void walk_volume(const RtDevScene &s, It &it, uint32_t cdv_idx, uint32_t self, float neg_inv_density, float tmin, float tmax,
-                        uint64_t volume_key, const float *scripted, uint32_t n_scripted, bool &found, Best &best) {
+                        uint64_t volume_key, const float *scripted, uint32_t n_scripted, bool &found, Best &best, bool tie_wins = false) {
     Pcg vr;
     vr.state = vr.inc = 0;
     uint32_t draw = 0, interval = 0;
@@ -705,8 +714,8 @@ RT_DEV void walk_volume(const RtDevScene &s, It &it, uint32_t cdv_idx, uint32_t 
             float t = fmaf(log_unit(1.0f - u), neg_inv_density, t1);
             if (t <= t2) {
                 uint32_t iv = interval << RT_CODE_INTERVAL_SHIFT;
-                if (in_range(t, tmin, tmax, found, best.t)) { best.t = t; best.ref = self; best.code = RT_CODE_SCATTER | iv | entry_code; found = true; return; }
-                if (has_exit && in_range(t2, tmin, tmax, found, best.t)) { best.t = t2; best.ref = self; best.code = iv | exit_code; found = true; return; }
+                if (in_range(t, tmin, tmax, found, best.t, tie_wins)) { best.t = t; best.ref = self; best.code = RT_CODE_SCATTER | iv | entry_code; found = true; return; }
+                if (has_exit && t2 < RT_INF && in_range(t2, tmin, tmax, found, best.t, tie_wins)) { best.t = t2; best.ref = self; best.code = iv | exit_code; found = true; return; }
             }
         }
         if (!has_exit) return;
@@ -718,9 +727,12 @@ RT_DEV void walk_volume(const RtDevScene &s, It &it, uint32_t cdv_idx, uint32_t 
 // over a primitive goes through the general event walk instead of its own few lines.
 // UNI: `ref` is the same in every lane (the list traversal), so the object's records are read once per wave.
 // WIDE: the scene holds a CSG shape of more than RT_CSG_LEAVES leaves; only kernels built for such scenes carry that walk.
-template <bool SIMPLE, bool MOTION = false, bool LEAN = false, bool UNI = false, bool WIDE = false>
+// DIRECT: plain primitives and volumes over one are tested by their own few lines instead of the general event walk (the
+// list traversal, whose kernels have the registers for it).
+// tie_wins: see in_range.
+template <bool SIMPLE, bool MOTION = false, bool LEAN = false, bool UNI = false, bool WIDE = false, bool DIRECT = UNI>
 RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmin, float tmax, uint64_t volume_key,
-                        const float *scripted, uint32_t n_scripted, bool &found, Best &best, float time = 0.0f) {
+                        const float *scripted, uint32_t n_scripted, bool &found, Best &best, float time = 0.0f, bool tie_wins = false) {
     uint32_t kind = (ref >> RT_KIND_SHIFT) & 7u, idx = ref & RT_INDEX_MASK;
     const uint32_t self = ref;           // what a hit is recorded under
     if (MOTION && kind == RT_KIND_MOTION) {
@@ -734,18 +746,18 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
     if (SIMPLE) {
         Span sp = sphere_span<UNI>(s, idx, o, d);
         if (span_valid(sp)) {
-            if (in_range(sp.t0, tmin, tmax, found, best.t)) { best.t = sp.t0; best.ref = self; best.code = 0; found = true; }
-            else if (in_range(sp.t1, tmin, tmax, found, best.t)) { best.t = sp.t1; best.ref = self; best.code = 0; found = true; }
+            if (in_range(sp.t0, tmin, tmax, found, best.t, tie_wins)) { best.t = sp.t0; best.ref = self; best.code = 0; found = true; }
+            else if (in_range(sp.t1, tmin, tmax, found, best.t, tie_wins)) { best.t = sp.t1; best.ref = self; best.code = 0; found = true; }
         }
         return;
     }
-    if (UNI && kind <= RT_KIND_QUAD) {
+    if (DIRECT && kind <= RT_KIND_QUAD) {
         // the list traversal knows the kind per wave: a plain primitive is tested directly, without
         // setting up the interval walk (which costs as much as a quad test)
-        Span sp = prim_span<UNI>(s, ref, o, d);
+        Span sp = prim_span<UNI>(s, ref, o, d, true);
         if (span_valid(sp)) {
-            if (in_range(sp.t0, tmin, tmax, found, best.t)) { best.t = sp.t0; best.ref = self; best.code = sp.tag0; found = true; }
-            else if (in_range(sp.t1, tmin, tmax, found, best.t)) { best.t = sp.t1; best.ref = self; best.code = sp.tag1; found = true; }
+            if (in_range(sp.t0, tmin, tmax, found, best.t, tie_wins)) { best.t = sp.t0; best.ref = self; best.code = sp.tag0; found = true; }
+            else if (in_range(sp.t1, tmin, tmax, found, best.t, tie_wins)) { best.t = sp.t1; best.ref = self; best.code = sp.tag1; found = true; }
         }
         return;
     }
@@ -758,18 +770,18 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
         const RtDevCdv cv = ld<UNI && !MOTION>(s.cdv + idx);
         shape = cv.base;
         neg_inv_density = cv.neg_inv_density;
-        if (UNI && ((shape >> RT_KIND_SHIFT) & 7u) != RT_KIND_CSG) {
+        if (DIRECT && ((shape >> RT_KIND_SHIFT) & 7u) != RT_KIND_CSG) {
             Span sp = prim_span<UNI>(s, shape, o, d);
             if (span_valid(sp))
-                volume_over_primitive<UNI>(s, idx, self, sp.t0, sp.t1, sp.tag0, sp.tag1, neg_inv_density, tmin, tmax, volume_key, scripted, found, best);
+                volume_over_primitive<UNI>(s, idx, self, sp.t0, sp.t1, sp.tag0, sp.tag1, neg_inv_density, tmin, tmax, volume_key, scripted, found, best, tie_wins);
             return;
         }
     }
     if (WIDE && is_wide_csg(s, shape)) {
         WideIter w;
         csg_begin_wide(s, shape, o, d, w);
-        if (volume) walk_volume(s, w, idx, self, neg_inv_density, tmin, tmax, volume_key, scripted, n_scripted, found, best);
-        else walk_boundary(s, w, self, tmin, tmax, found, best);
+        if (volume) walk_volume(s, w, idx, self, neg_inv_density, tmin, tmax, volume_key, scripted, n_scripted, found, best, tie_wins);
+        else walk_boundary(s, w, self, tmin, tmax, found, best, tie_wins);
         return;
     }
     CsgIter it;
@@ -779,12 +791,12 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
             // one interval: entry, else exit (Shaders.metal:182-199 on a two-hit enumerator)
             const float t0 = it.tin[0], t1 = it.tout[0];
             if (!(it.entered & 1u)) {
-                if (in_range(t0, tmin, tmax, found, best.t)) { best.t = t0; best.ref = self; best.code = (uint32_t)it.tags & 7u; found = true; }
-                else if (in_range(t1, tmin, tmax, found, best.t)) { best.t = t1; best.ref = self; best.code = ((uint32_t)it.tags >> 3) & 7u; found = true; }
+                if (in_range(t0, tmin, tmax, found, best.t, tie_wins)) { best.t = t0; best.ref = self; best.code = (uint32_t)it.tags & 7u; found = true; }
+                else if (in_range(t1, tmin, tmax, found, best.t, tie_wins)) { best.t = t1; best.ref = self; best.code = ((uint32_t)it.tags >> 3) & 7u; found = true; }
             }
             return;
         }
-        walk_boundary(s, it, self, tmin, tmax, found, best);
+        walk_boundary(s, it, self, tmin, tmax, found, best, tie_wins);
         return;
     }
     // Constant-density volume, RenderableImpl.h:737-777: one free-flight draw per interval of
@@ -793,10 +805,10 @@ RT_DEV void test_object(const RtDevScene &s, uint32_t ref, f3 o, f3 d, float tmi
         // a primitive base has one interval: no event walk needed
         if (it.entered & 1u) return;
         volume_over_primitive<UNI>(s, idx, self, it.tin[0], it.tout[0], (uint32_t)it.tags & 7u, ((uint32_t)it.tags >> 3) & 7u, neg_inv_density,
-                                   tmin, tmax, volume_key, scripted, found, best);
+                                   tmin, tmax, volume_key, scripted, found, best, tie_wins);
         return;
     }
-    walk_volume(s, it, idx, self, neg_inv_density, tmin, tmax, volume_key, scripted, n_scripted, found, best);
+    walk_volume(s, it, idx, self, neg_inv_density, tmin, tmax, volume_key, scripted, n_scripted, found, best, tie_wins);
 }
 
 // ------------------------------------------------------------------ BVH traversal (extend)
@@ -968,9 +980,15 @@ RT_DEV void trav_node16(const uint4 *nodes16, Trav &t, float tmin, uint32_t *sta
     float limit = t.best.t;
     uint4 a, b;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (TOP_BYTES && t.cur < TOP_BYTES) {
-        const lds_u4 *l = (const lds_u4 *)(top_lds + t.cur);
-        a = l[0]; b = l[1];
+    if (TOP_BYTES) {
+        // The two homes are read by different instructions on purpose: given two pointers to choose from, the compiler
+        // merges them into one flat pointer and reads the node with five flat loads (measured: half the speed).
+        const bool in_top = t.cur < TOP_BYTES;
+        if (!in_top) { a = n[0]; b = n[1]; }
+        if (in_top) {
+            const uint32_t addr = top_lds + t.cur;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(addr) : "memory");
+        }
     } else
 #endif
     { a = n[0]; b = n[1]; }

@@ -112,7 +112,7 @@ struct RtScene {
     std::vector<float> bulk_spheres;       // cx, cy, cz, r
     std::vector<uint32_t> bulk_mats;
     int bvh_builder = RT_BVH_SAH;
-    uint32_t refill = 48;
+    uint32_t refill = 0;               // 0: the kernel's own default (48; 28 for the deep-tree kernel that keeps the top of the tree in LDS)
     int node_min = -1;      // -1: chosen at render time from what the scene holds
     int heavy_min = -1;     // -1: default
     int traversal = RT_TRAVERSAL_AUTO;
@@ -127,6 +127,7 @@ struct RtScene {
     uint32_t feat = 0;
     RtSceneStats stats{};
     RtKernelTimer timer;
+    RtWfProbe wf_probe;            // live-count read-back of the wavefront loop (created by the first wavefront render)
 
     ~RtScene() { release(); }
     void release() {
@@ -1477,6 +1478,7 @@ namespace {
 // of cylinders, boxes, CSG shapes and volumes cost several node steps and wait for fuller waves.
 uint32_t fused_knobs(const RtScene *sc, const RtDevCamera &cam) {
     const uint32_t node_min = sc->node_min >= 0 ? (uint32_t)sc->node_min : 8u;
+    // refill = 0 goes through as it is: the launcher puts the chosen kernel's default in
     return sc->refill | (node_min << 8) | (sc->profile_phases ? 0x10000u : 0u) | (sc->use_nodes16 ? 0x20000u : 0u) |
            ((cam.defocus ? 16u : 0u) << 18) | (((sc->feat & RT_FEAT_XPRIM) ? 65u : ((sc->feat & RT_FEAT_MOTION) ? 20u : 12u)) << 25);
 }
@@ -1516,7 +1518,7 @@ int rt_render(RtScene *sc, const RtCameraConfig *cc, const RtRenderConfig *rc, u
         if (workspace_bytes < rt_wavefront_bytes((uint32_t)width * (uint32_t)height))
             return fail(RT_ERR_INVALID, "workspace too small");
         e = rt_render_wavefront(sc->dev, sc->feat, cam, r, accum_dev, workspace_dev, workspace_bytes, as_stream(stream), &sc->timer,
-                                sc->ctx->cus);
+                                sc->ctx->cus, &sc->wf_probe, sc->stats.bvh_depth);
     } else {
         return fail(RT_ERR_INVALID, "unknown pipeline");
     }

@@ -18,6 +18,7 @@
 // Both draw sample s of pixel (x, y) from the same generator stream, so they are the same
 // estimator sample for sample.
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 
 #include "rt_device.h"
@@ -38,6 +39,9 @@
 #endif
 #ifndef RT_WPS_MOVING_SPHERES
 #define RT_WPS_MOVING_SPHERES 6   // ... of the spheres-and-moving-spheres kernel
+#endif
+#ifndef RT_TOP_NODES
+#define RT_TOP_NODES 448       // nodes of a deep tree's head kept in LDS by its kernel (14 KB next to a 512-thread workgroup's 32-KB stack: three workgroups per CU)
 #endif
 #ifndef RT_DOUBLE_STEP
 #define RT_DOUBLE_STEP 24u       // lanes on inner nodes from which a second node step follows the first without a new count (+1.6 % on random spheres)
@@ -421,6 +425,10 @@ RT_DEV uint32_t *wf_counter(const WfQueues &q, int queue, uint32_t shard) {
     return q.counts + ((uint32_t)queue * RT_WF_SHARDS + shard) * RT_WF_COUNTER_STRIDE;
 }
 
+#define RT_WF_NEXT_OFFSET (2u * RT_WF_SHARDS * RT_WF_COUNTER_STRIDE)       // words: the shards' `next` counters follow the live counters
+#define RT_WF_REFILL 24u
+RT_DEV uint32_t *wf_next(const WfQueues &q, uint32_t shard) { return q.counts + RT_WF_NEXT_OFFSET + shard * RT_WF_COUNTER_STRIDE; }
+
 // Ray generation: path i of the batch is sample i / npix of pixel i % npix.
 __global__ __launch_bounds__(RT_BLOCK) void k_wf_raygen(WfQueues q, RtDevCamera cam, RtDevRender rc, uint32_t batch_spp) {
     uint32_t npix = rc.width * rc.height, total = npix * batch_spp;
@@ -430,6 +438,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_raygen(WfQueues q, RtDevCamera 
         uint32_t cnt = (full / RT_WF_SHARDS) * 256u + (sh < full % RT_WF_SHARDS ? 256u : 0u) + (sh == full % RT_WF_SHARDS ? rem : 0u);
         *wf_counter(q, 0, sh) = cnt;
         *wf_counter(q, 1, sh) = 0;
+        *wf_next(q, sh) = 0;
     }
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < total; i += gridDim.x * RT_BLOCK) {
         uint32_t pix = i % npix, sidx = i / npix;
@@ -448,27 +457,106 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_raygen(WfQueues q, RtDevCamera 
     }
 }
 
-// Extend: closest hit of every live path of queue `cur`.
-template <int FEAT>
+// Extend: closest hit of every live path of queue `cur`.  Waves are persistent over their shard of the queue: a lane
+// whose ray has found its closest hit stores it and, once `WF_REFILL` lanes of the wave are free, the free lanes take
+// the shard's next paths (one atomic per wave on the shard's `next` counter), so the node steps and leaf tests of a wave
+// run on rays that are still walking instead of on the longest walk of a fixed set of 64.  The walk itself is the fused
+// kernel's: per-lane resumable traversal, stack in LDS, node steps and leaf tests as wave-wide phases, 32-byte nodes
+// with byte-offset references where the scene has them.
+// STACK: stack entries per lane (16 for trees of at most 16 levels: 16 KB of LDS per workgroup instead of 24).
+template <int FEAT, bool NODE16, int STACK>
 __global__ __launch_bounds__(RT_BLOCK) void k_wf_extend(RtDevScene s, WfQueues q, int cur) {
-    __shared__ uint32_t stack[RT_STACK_DEPTH * RT_BLOCK];
-    const uint32_t shard = blockIdx.x % RT_WF_SHARDS, lb = blockIdx.x / RT_WF_SHARDS, nb = gridDim.x / RT_WF_SHARDS;
+    __shared__ uint32_t stack_mem[STACK * RT_BLOCK];
+    constexpr bool SIMPLE = !(FEAT & RT_FEAT_XPRIM);
+    constexpr bool MOTION = (FEAT & RT_FEAT_MOTION) != 0;
+    constexpr bool WIDE = (FEAT & RT_FEAT_WIDE_CSG) != 0;
+    const uint32_t shard = blockIdx.x % RT_WF_SHARDS;
     const uint32_t count = *wf_counter(q, cur, shard);
-    if (lb == 0 && threadIdx.x == 0) *wf_counter(q, cur ^ 1, shard) = 0;   // shade appends to the other queue
-    for (uint32_t j = lb * RT_BLOCK + threadIdx.x; j < count; j += nb * RT_BLOCK) {
-        uint32_t i = shard * q.shard_cap + j;
-        float4 ro = q.ray_o[cur][i], rd = q.ray_d[cur][i];
-        uint64_t key = 0;
-        if (FEAT & RT_FEAT_XPRIM) {
-            uint4 r = q.rng[cur][i];
-            key = ((uint64_t)r.y << 32) | r.x;
+    if (blockIdx.x / RT_WF_SHARDS == 0 && threadIdx.x == 0) *wf_counter(q, cur ^ 1, shard) = 0;   // shade appends to the other queue
+    uint32_t *next = wf_next(q, shard);
+    const uint32_t lane = lane_id();
+    uint32_t *stack = stack_mem + threadIdx.x;
+    const float4 *nodes = (const float4 *)s.nodes;
+    const uint4 *nodes16 = (const uint4 *)s.nodes16;
+    const uint32_t root = (NODE16 && !(s.root & RT_REF_LEAF)) ? s.root * 32u : s.root;
+    const uint32_t node_min = 8u, leaf_max = SIMPLE ? 12u : 65u, heavy_min = 8u;
+    Trav t;
+    trav_begin(t, RT_REF_NONE, mk3(0, 0, 0), mk3(0, 0, 1), RT_INF, stack);
+    // (Measured and left out: reading a lane's next ray from the queue while it still walks the current one.  Loads
+    // return in order, so the first node fetch after a hand-out waited for the queue read all the same: 2.70 -> 2.36
+    // Gsamples/s on the random-spheres workload.)
+    uint32_t slot = 0;
+    bool busy = false, more = count != 0u;
+    uint64_t key = 0;
+    float time = 0.f;
+    while (true) {
+        if (busy && t.cur == RT_REF_NONE) {
+            q.hit[slot] = make_float4(t.best.t, __uint_as_float(t.found ? t.best.ref : RT_REF_NONE), __uint_as_float(t.best.code), 0.f);
+            busy = false;
         }
-        Best b;
-        float time = 0.f;
-        if (FEAT & RT_FEAT_MOTION) time = q.thr[cur][i].w;
-        bool found = trace<!(FEAT & RT_FEAT_XPRIM), (FEAT & RT_FEAT_MOTION) != 0, (FEAT & RT_FEAT_WIDE_CSG) != 0>(s, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), RT_T_MIN,
-                                                                                RT_INF, key, nullptr, 0, stack + threadIdx.x, b, time);
-        q.hit[i] = make_float4(b.t, __uint_as_float(found ? b.ref : RT_REF_NONE), __uint_as_float(b.code), 0.f);
+        const uint64_t free_mask = __ballot(!busy);
+        if (more && free_mask) {
+            const uint32_t n_free = (uint32_t)__popcll(free_mask);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(next, n_free);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base + n_free >= count) more = false;          // the shard has nothing beyond this hand-out
+            if (!busy) {
+                const uint32_t j = base + prefix_rank(free_mask);
+                if (j < count) {
+                    slot = shard * q.shard_cap + j;
+                    const float4 ro = q.ray_o[cur][slot], rd = q.ray_d[cur][slot];
+                    if (FEAT & RT_FEAT_XPRIM) {
+                        const uint4 r = q.rng[cur][slot];
+                        key = ((uint64_t)r.y << 32) | r.x;
+                    }
+                    if (MOTION) time = q.thr[cur][slot].w;
+                    trav_begin(t, root, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), RT_INF, stack);
+                    busy = true;
+                }
+            }
+        }
+        if (__ballot(busy) == 0) break;                        // nothing in flight, nothing left to take
+        while (true) {
+            while (true) {
+                const bool inner = !(t.cur & RT_REF_LEAF);
+                const uint32_t n_inner = (uint32_t)__popcll(__ballot(inner));
+                if (n_inner == 0) break;
+                const bool waits = !inner && t.cur != RT_REF_NONE;
+                uint32_t n_ready = (uint32_t)__popcll(__ballot(waits));
+                if (!SIMPLE) {
+                    const uint32_t n_heavy = (uint32_t)__popcll(__ballot(waits && ((t.cur >> RT_KIND_SHIFT) & 7u) >= RT_KIND_CSG));
+                    if (n_heavy < heavy_min) n_ready -= n_heavy;
+                }
+                if ((n_inner < node_min && n_ready) || n_ready >= leaf_max) break;
+                if (inner) {
+                    if (NODE16) trav_node16(nodes16, t, RT_T_MIN, stack);
+                    else trav_node(nodes, t, RT_T_MIN, stack);
+                }
+                if (n_inner >= RT_DOUBLE_STEP) {
+                    if (!(t.cur & RT_REF_LEAF)) {
+                        if (NODE16) trav_node16(nodes16, t, RT_T_MIN, stack);
+                        else trav_node(nodes, t, RT_T_MIN, stack);
+                    }
+                }
+            }
+            bool at_leaf = (t.cur & RT_REF_LEAF) && t.cur != RT_REF_NONE;
+            if (!SIMPLE) {
+                const bool heavy = at_leaf && ((t.cur >> RT_KIND_SHIFT) & 7u) >= RT_KIND_CSG;
+                const uint32_t n_heavy = (uint32_t)__popcll(__ballot(heavy));
+                if (n_heavy && n_heavy < heavy_min) {
+                    const bool others = __ballot(!(t.cur & RT_REF_LEAF) || (at_leaf && !heavy)) != 0;
+                    if (others) at_leaf = at_leaf && !heavy;
+                }
+            }
+            if (at_leaf) {
+                test_object<SIMPLE, MOTION, false, false, WIDE>(s, t.cur & ~RT_REF_LEAF, t.o, t.d, RT_T_MIN, RT_INF, key, nullptr, 0, t.found, t.best, time);
+                trav_pop(t, stack);
+            }
+            const uint32_t n_active = (uint32_t)__popcll(__ballot(t.cur != RT_REF_NONE));
+            // back to the hand-out once enough lanes are free; when the shard is used up, only when the wave has finished
+            if (n_active == 0 || (more && 64u - n_active >= RT_WF_REFILL)) break;
+        }
     }
 }
 
@@ -484,6 +572,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_shade(RtDevScene s, WfQueues q,
     const uint32_t shard = blockIdx.x % RT_WF_SHARDS, lb = blockIdx.x / RT_WF_SHARDS, nb = gridDim.x / RT_WF_SHARDS;
     const uint32_t count = *wf_counter(q, cur, shard);
     const int nxt = cur ^ 1;
+    if (lb == 0 && threadIdx.x == 0) *wf_next(q, shard) = 0;          // the next extend launch hands out from the start again
     for (uint32_t jb = lb * RT_BLOCK; jb < count; jb += nb * RT_BLOCK) {     // uniform over the workgroup
         uint32_t j = jb + threadIdx.x, i = shard * q.shard_cap + j;
         bool survive = false;
@@ -663,7 +752,11 @@ __global__ __launch_bounds__(BLOCK, WPS) void k_fused(RtDevScene s, const RtDevC
         f3 o = t.o, d = t.d;
         RT_PROF_BEGIN();
         const bool shading = has_path && t.cur == RT_REF_NONE;
-        if (has_path && t.cur == RT_REF_NONE) {
+        // (Measured and left out: holding lanes whose hit wants a texture evaluated from noise tables or an image - five
+        // octaves of Perlin noise cost some 600 instructions, usually for one or two lanes of the wave - until 4 / 8 / 16
+        // of them can be shaded together: 5.18 -> 5.10 / 5.01 / 4.77 Gsamples/s on the CSG and textures workload, 6.19 ->
+        // 6.15 / 6.12 / 5.94 on the Kit's first world.  A held lane is a lane that walks no ray.)
+        if (shading) {
             bool alive = shade_path<FEAT>(s, background, rc.max_depth, t.found, t.best, o, d, thr, rad, depth, g, time);
             if (alive) {
                 start = true;
@@ -770,6 +863,11 @@ __global__ __launch_bounds__(BLOCK, WPS) void k_fused(RtDevScene s, const RtDevC
             continue;
         }
         // ---- extend phase
+        // (Measured and left out: noting, per lane, the objects whose box the ray enters and then letting every lane test
+        // one of its own noted objects per round - two fog boxes in one round of volume code instead of two.  The records
+        // then come through per-lane vector loads, three dependent ones deep (list entry, volume, primitive), where the
+        // uniform form reads them through the scalar cache: Cornell with smoke 8.26 -> 6.98 Gsamples/s, the Kit's first
+        // world 5.85 -> 5.59.)
         if (LIST) {
             // Array<any Hittable>.hit, RayTracingKit/Hittable.swift:662-671: closest hit over the list,
             // the range shrinking as hits are found.  The object is the same in all lanes (its record
@@ -971,25 +1069,45 @@ int rt_current_device_cus() {
 
 template <int FEAT>
 static hipError_t wavefront_batch(const RtDevScene &s, const RtDevCamera &cam, const RtDevRender &rc, uint32_t batch_spp,
-                                  const WfQueues &q, float *accum, hipStream_t stream, RtKernelTimer *timer, int grid) {
+                                  const WfQueues &q, float *accum, hipStream_t stream, RtKernelTimer *timer, int grid, RtWfProbe *probe,
+                                  bool shallow) {
     uint32_t npix = rc.width * rc.height;
     k_wf_raygen<<<grid, RT_BLOCK, 0, stream>>>(q, cam, rc, batch_spp);
+    const bool probing = probe && probe->init();
+    const uint32_t first_probe = 1;
+    // Paths only ever leave the queues, so the live count read RT_WF_LAG bounces ago bounds this bounce's: late bounces
+    // (a few thousand paths inside glass) get a grid of their size instead of one that fills the chip - an extend launch
+    // of 2048 workgroups costs 26 us even when it finds nothing to do.
+    uint32_t live_bound = npix * batch_spp;
+    const int full_grid = grid;
     for (uint32_t bounce = 0; bounce < rc.max_depth; bounce++) {
         int cur = (int)(bounce & 1u);
+        grid = std::min(full_grid, (int)((live_bound + 1023u) / 1024u));
+        grid = std::max((int)RT_WF_SHARDS, (grid + (int)RT_WF_SHARDS - 1) / (int)RT_WF_SHARDS * (int)RT_WF_SHARDS);
         if (timer) timer->begin(stream);
-        k_wf_extend<FEAT><<<grid, RT_BLOCK, 0, stream>>>(s, q, cur);
+        if (s.nodes16 && shallow) k_wf_extend<FEAT, true, 16><<<grid, RT_BLOCK, 0, stream>>>(s, q, cur);
+        else if (s.nodes16) k_wf_extend<FEAT, true, RT_STACK_DEPTH><<<grid, RT_BLOCK, 0, stream>>>(s, q, cur);
+        else k_wf_extend<FEAT, false, RT_STACK_DEPTH><<<grid, RT_BLOCK, 0, stream>>>(s, q, cur);
         if (timer) timer->end(stream);
         k_wf_shade<FEAT><<<grid, RT_BLOCK, 0, stream>>>(s, q, cur, cam.background, rc.max_depth);
-        // the queues drain geometrically: look at the live count now and then, and stop early
-        if (bounce >= 7 && (bounce & 3u) == 3u && bounce + 1 < rc.max_depth) {
-            uint32_t header[RT_WF_HEADER / 4];
-            hipError_t e = hipMemcpyAsync(header, q.counts, RT_WF_HEADER, hipMemcpyDeviceToHost, stream);
+        if (!probing || bounce + 1 >= rc.max_depth) continue;
+        // the queues drain geometrically: the live count of the queue just filled goes to the host without a stream
+        // synchronisation, and is looked at RT_WF_LAG bounces later (see RtWfProbe)
+        if (bounce >= first_probe) {
+            const uint32_t slot = bounce % RT_WF_PROBES;
+            hipError_t e = hipMemcpyAsync(probe->host + slot * 256u, q.counts + (uint32_t)(cur ^ 1) * RT_WF_SHARDS * RT_WF_COUNTER_STRIDE, 1024, hipMemcpyDeviceToHost, stream);
             if (e != hipSuccess) return e;
-            e = hipStreamSynchronize(stream);
+            e = hipEventRecord(probe->ev[slot], stream);
+            if (e != hipSuccess) return e;
+        }
+        if (bounce >= first_probe + RT_WF_LAG) {
+            const uint32_t slot = (bounce - RT_WF_LAG) % RT_WF_PROBES;
+            hipError_t e = hipEventSynchronize(probe->ev[slot]);
             if (e != hipSuccess) return e;
             uint32_t live = 0;
-            for (uint32_t sh = 0; sh < RT_WF_SHARDS; sh++) live += header[((uint32_t)(cur ^ 1) * RT_WF_SHARDS + sh) * RT_WF_COUNTER_STRIDE];
+            for (uint32_t sh = 0; sh < RT_WF_SHARDS; sh++) live += probe->host[slot * 256u + sh * RT_WF_COUNTER_STRIDE];
             if (live == 0) break;
+            live_bound = live;
         }
     }
     k_wf_accumulate<<<blocks_for(npix), RT_BLOCK, 0, stream>>>(q.sample_rad, npix, batch_spp, accum);
@@ -997,7 +1115,9 @@ static hipError_t wavefront_batch(const RtDevScene &s, const RtDevCamera &cam, c
 }
 
 hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc, float *accum,
-                               void *workspace, size_t workspace_bytes, hipStream_t stream, RtKernelTimer *timer, int cus) {
+                               void *workspace, size_t workspace_bytes, hipStream_t stream, RtKernelTimer *timer, int cus, RtWfProbe *probe,
+                               uint32_t bvh_depth) {
+    const bool shallow = bvh_depth <= 16;
     uint32_t npix = rc.width * rc.height;
     if (npix == 0 || rc.spp == 0) return hipSuccess;
     if (workspace_bytes < rt_wavefront_bytes(npix)) return hipErrorInvalidValue;
@@ -1019,13 +1139,13 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
         grid = (grid + (int)RT_WF_SHARDS - 1) / (int)RT_WF_SHARDS * (int)RT_WF_SHARDS;
         hipError_t e;
         switch ((feat & RT_FEAT_WIDE_CSG) ? 15u : (feat & 7u)) {
-        case 15: e = wavefront_batch<15>(s, cam, r, batch, q, accum, stream, timer, grid); break;
-        case 0: e = wavefront_batch<0>(s, cam, r, batch, q, accum, stream, timer, grid); break;
-        case 1: e = wavefront_batch<1>(s, cam, r, batch, q, accum, stream, timer, grid); break;
-        case 2: e = wavefront_batch<2>(s, cam, r, batch, q, accum, stream, timer, grid); break;
-        case 3: e = wavefront_batch<3>(s, cam, r, batch, q, accum, stream, timer, grid); break;
-        case 5: e = wavefront_batch<5>(s, cam, r, batch, q, accum, stream, timer, grid); break;
-        default: e = wavefront_batch<7>(s, cam, r, batch, q, accum, stream, timer, grid); break;
+        case 15: e = wavefront_batch<15>(s, cam, r, batch, q, accum, stream, timer, grid, probe, shallow); break;
+        case 0: e = wavefront_batch<0>(s, cam, r, batch, q, accum, stream, timer, grid, probe, shallow); break;
+        case 1: e = wavefront_batch<1>(s, cam, r, batch, q, accum, stream, timer, grid, probe, shallow); break;
+        case 2: e = wavefront_batch<2>(s, cam, r, batch, q, accum, stream, timer, grid, probe, shallow); break;
+        case 3: e = wavefront_batch<3>(s, cam, r, batch, q, accum, stream, timer, grid, probe, shallow); break;
+        case 5: e = wavefront_batch<5>(s, cam, r, batch, q, accum, stream, timer, grid, probe, shallow); break;
+        default: e = wavefront_batch<7>(s, cam, r, batch, q, accum, stream, timer, grid, probe, shallow); break;
         }
         if (e != hipSuccess) return e;
     }
@@ -1055,6 +1175,8 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
         if (dev >= 0 && dev < 64) occ_of_device[dev].store(occ, std::memory_order_relaxed);
     }
     if (prepare_only) return hipSuccess;
+    static const bool show_occupancy = getenv("RT_SHOW_OCCUPANCY") != nullptr;       // diagnostic: what the runtime answered
+    if (show_occupancy) fprintf(stderr, "k_fused<feat %d, stack %d, wps %d, block %d, top %d>: %d workgroups per CU\n", FEAT, STACK, WPS, BLOCK, TOP, occ);
     if (DEEP) occ = std::min(occ, 2048 / BLOCK);        // the deep-stack columns are sized for 2048 threads per CU
     int grid = cus * occ;
     // Work items = tiles x sample chunks.  Large chunks leave the waves finishing at different
@@ -1075,6 +1197,10 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     uint32_t counters_log2 = 0;
     while ((2u << counters_log2) <= RT_ITEM_COUNTERS && (16u << counters_log2) <= (uint32_t)grid) counters_log2++;
     const bool prof = (knobs & 0x10000u) != 0;
+    // refill threshold left at 0 by the caller: 48 finished or free lanes before a wave leaves its traversal loop; the
+    // kernel that reads the top of the tree from LDS does better with fuller waves (28: +12 % over 48 there, where the
+    // plain deep-tree kernel loses 2 % with 32)
+    if ((knobs & 255u) == 0u) knobs |= TOP ? 28u : 48u;
     k_fused_setup<<<1, 256, 0, stream>>>(counter, cam);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1122,17 +1248,15 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
         if (bvh_depth <= 16) return RT_FUSED(0, 16, RT_WPS0);
         // a deep tree (a million spheres) waits on memory, not on the ALUs: 8 waves per SIMD with
         // the rare deep stack entries in global memory beat 5 waves with the whole stack in LDS
-        if (n16 && (workspace_bytes >= rt_fused_workspace_bytes(cus) || prepare_only)) {
-            // experiment switch: the top of the tree in LDS, shared by a larger workgroup
-            static const int variant = getenv("RT_DEEP_VARIANT") ? atoi(getenv("RT_DEEP_VARIANT")) : 0;
-            if (variant == 1) return fused_launch<0, 16, 6, true, true, false, 512, 448>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
-            if (variant == 2) return fused_launch<0, 16, 7, true, true, false, 896, 416>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
-            if (variant == 3) return fused_launch<0, 12, 7, true, true, false, 896, 832>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
-            if (variant == 4) return fused_launch<0, 16, 6, true, true, false, 512, 0>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
-        }
         if (workspace_bytes >= rt_fused_workspace_bytes(cus) || prepare_only) {
-            hipError_t e = n16 ? fused_launch<0, 16, RT_WPS_DEEP, true, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only)
-                               : fused_launch<0, 16, RT_WPS_DEEP, false, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
+            // With 32-byte nodes: 512-thread workgroups that keep the RT_TOP_NODES nodes at the head of the node array
+            // (the largest boxes: the builder of a deep tree puts them there) in LDS, 6 waves per SIMD.  RT_DEEP_PLAIN=1
+            // in the environment runs the kernel without the LDS copy (7 waves per SIMD), for comparison.
+            static const bool plain = getenv("RT_DEEP_PLAIN") != nullptr;
+            hipError_t e;
+            if (n16 && !plain) e = fused_launch<0, 16, 6, true, true, false, 512, RT_TOP_NODES>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
+            else if (n16) e = fused_launch<0, 16, RT_WPS_DEEP, true, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
+            else e = fused_launch<0, 16, RT_WPS_DEEP, false, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
             if (!prepare_only) return e;
         }
         return RT_FUSED(0, RT_STACK_DEPTH, 5);

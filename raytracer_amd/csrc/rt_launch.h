@@ -65,6 +65,32 @@ struct RtKernelTimer {
     ~RtKernelTimer() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); }
 };
 
+// How the wavefront loop learns that its queues have run empty without ever draining the stream: after the shade
+// launch of a bounce the eight live counters of the next queue are copied to pinned host memory and an event is
+// recorded; RT_WF_LAG bounces later the host waits for that event only - the bounces launched since are still queued, so
+// the GPU stays busy - and stops launching once the copy says that no path is left.  Created on first use, owned by
+// the scene (one render call at a time per scene, as everywhere in this interface).
+#define RT_WF_LAG 2
+#define RT_WF_PROBES 4
+struct RtWfProbe {
+    uint32_t *host = nullptr;          // RT_WF_PROBES x 256 words of pinned memory: one queue's counters per slot
+    hipEvent_t ev[RT_WF_PROBES] = {};
+    bool ready = false, failed = false;
+
+    bool init() {
+        if (ready || failed) return ready;
+        if (hipHostMalloc((void **)&host, RT_WF_PROBES * 1024, hipHostMallocDefault) != hipSuccess) { host = nullptr; failed = true; return false; }
+        for (int i = 0; i < RT_WF_PROBES; i++)
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { failed = true; return false; }
+        ready = true;
+        return true;
+    }
+    ~RtWfProbe() {
+        for (int i = 0; i < RT_WF_PROBES; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
+        if (host) (void)hipHostFree(host);
+    }
+};
+
 // Layout of the wavefront pipeline's workspace for `capacity` paths.
 struct RtWavefrontBuffers {
     float4 *ray_o[2], *ray_d[2], *thr[2], *rad[2];
@@ -98,7 +124,7 @@ hipError_t rt_launch_progressive_present(const float *pass_sum, uint32_t spp, ui
 // count of the device the scene lives on (grids and the deep-stack columns are sized by it).
 hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCamera &cam, RtDevRender rc,
                                float *accum, void *workspace, size_t workspace_bytes, hipStream_t stream,
-                               RtKernelTimer *timer, int cus);
+                               RtKernelTimer *timer, int cus, RtWfProbe *probe = nullptr, uint32_t bvh_depth = RT_STACK_DEPTH);
 // knobs2: bits 0-6 = heavy_min (lanes that must wait at a CSG shape / volume / moving object before
 // the wave runs that code; 0 or 1 = never held back).
 // prepare_only: no launch; makes the runtime queries a later call of the same scene would make

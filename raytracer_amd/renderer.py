@@ -30,6 +30,16 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _no_stream:
+    """`with` block that leaves the current stream alone."""
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
 class Context:
     def __init__(self, device_ordinal=0):
         self.device_ordinal = device_ordinal
@@ -312,11 +322,15 @@ class ProgressiveView:
     SAMPLES_PER_PASS = 1      # ContentView.swift:202
     MAX_DEPTH = 10
 
-    def __init__(self, scene, width, height, seed=0, **renderer_args):
+    def __init__(self, scene, width, height, seed=0, overlap=True, **renderer_args):
+        """overlap: successive passes alternate between two streams, each with its own pass-sum buffer and
+        workspace, so that pass n + 1 starts on the compute units pass n's last, long paths leave idle; the
+        present steps stay in pass order (an event per pass).  The words and pixels are the same either way."""
         from .scene import WyRand
         self.renderer = Renderer(scene, width, height, **renderer_args)
         self.seeds = WyRand(seed)             # stands in for SystemRandomNumberGenerator (:201)
         self.paused = False
+        self.overlap = overlap
         self._alloc()
 
     def _alloc(self):
@@ -326,6 +340,19 @@ class ProgressiveView:
         self.drawable = torch.zeros((r.height, r.width, 4), dtype=torch.uint8, device=dev)  # bgra8Unorm
         self.pass_counter = 0
         self.paused = False
+        # per pass slot: stream, pass sums, workspace, event recorded after the slot's present
+        self._slots = []
+        for k in range(2 if self.overlap else 1):
+            # one stream of each priority class: the two then sit on different hardware queues (two streams of one class
+            # may share a queue, and passes on a shared queue do not overlap)
+            stream = torch.cuda.Stream(device=dev, priority=-k) if self.overlap else None
+            sums = r.accum if k == 0 else torch.zeros_like(r.accum)
+            work = r.workspace if k == 0 else torch.empty_like(r.workspace)
+            self._slots.append((stream, sums, work, torch.cuda.Event()))
+        self._last = None                      # slot of the latest pass
+        if self.overlap:
+            for stream, _, _, _ in self._slots:
+                stream.wait_stream(torch.cuda.current_stream(dev))      # after the allocations above
 
     # ---- Renderer.scene didSet / mtkView(_:drawableSizeWillChange:)  (:107-113, :172-180)
     def set_camera(self, camera):
@@ -334,12 +361,18 @@ class ProgressiveView:
             self.set_needs_redraw()
 
     def resize(self, width, height):
+        self.wait()
         self.renderer.resize(width, height)
         self._alloc()
 
     def set_needs_redraw(self):
         self.pass_counter = 0
         self.paused = False
+
+    def wait(self):
+        """Makes the caller's current stream wait for the latest pass (its drawable and running mean)."""
+        if self.overlap and self._last is not None:
+            torch.cuda.current_stream(self.renderer.ctx.device).wait_event(self._slots[self._last][3])
 
     # ---- Renderer.draw(in:)  (:182-224)
     def draw(self, rng_seed=None):
@@ -351,13 +384,21 @@ class ProgressiveView:
             self.paused = True
         r = self.renderer
         seed = self.seeds.next() if rng_seed is None else rng_seed
-        r.accum.zero_()
+        slot = self.pass_counter & 1 if self.overlap else 0
+        stream, sums, work, done = self._slots[slot]
         rc = RenderConfig(self.SAMPLES_PER_PASS, self.MAX_DEPTH, self.pass_counter, seed, 0).impl
         cc = r.camera.impl
-        check(lib.rt_render(r.native.h, C.byref(cc), C.byref(rc), 0, r.pipeline, r.width, r.height, r.accum.data_ptr(),
-                            r.workspace.data_ptr(), r.workspace.numel(), _stream()))
-        check(lib.rt_progressive_present(r.ctx.h, r.accum.data_ptr(), self.SAMPLES_PER_PASS, self.pass_counter,
-                                         self.acc.data_ptr(), self.drawable.data_ptr(), r.width, r.height, _stream()))
+        with torch.cuda.stream(stream) if stream is not None else _no_stream():
+            sums.zero_()
+            check(lib.rt_render(r.native.h, C.byref(cc), C.byref(rc), 0, r.pipeline, r.width, r.height, sums.data_ptr(),
+                                work.data_ptr(), work.numel(), _stream()))
+            if self.overlap and self._last is not None:
+                torch.cuda.current_stream().wait_event(self._slots[self._last][3])      # the running mean is updated in pass order
+            check(lib.rt_progressive_present(r.ctx.h, sums.data_ptr(), self.SAMPLES_PER_PASS, self.pass_counter,
+                                             self.acc.data_ptr(), self.drawable.data_ptr(), r.width, r.height, _stream()))
+            done.record()
+        r.accum = sums                          # this pass alone, as before
+        self._last = slot
         return True
 
     def running_mean(self):

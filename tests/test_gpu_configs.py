@@ -39,13 +39,13 @@ def ctx():
 # relative difference of the image means
 CONVERGED = [
     # measured on MI355X: 65.8 dB / 0.975, 57.8 dB / 0.997, 65.8 dB / 0.986; means equal to 1.4e-4
-    ("cfg2_random_spheres_1080p", 64, 60.0, 0.96, 5e-3),
-    ("cfg3_cornell_smoke_1080p", 64, 52.0, 0.99, 5e-3),
-    ("cfg4_csg_textured_1080p", 64, 60.0, 0.975, 5e-3),
-    # the rows next to the path.  Motion blur: 61.5 dB / 0.977 / 1.8e-4.  The Kit's first world: 37.9 dB / 0.921 / 7.8e-3 -
-    # a small bright light behind a defocused camera: the few paths that a float rounding sends elsewhere carry a lot of energy
-    ("f2_bouncing_spheres_1080p", 32, 56.0, 0.96, 5e-3),
-    ("f3_kit_world1_1080p", 32, 34.0, 0.90, 2e-2),
+    ("cfg2_random_spheres_1080p", 64, 60.0, 0.96, 1e-3),
+    ("cfg3_cornell_smoke_1080p", 64, 52.0, 0.99, 1e-3),
+    ("cfg4_csg_textured_1080p", 64, 60.0, 0.975, 1e-3),
+    # the rows next to the path.  Motion blur: 61.5 dB / 0.977 / 1.8e-4.  The Kit's first world: 58.7 dB / 0.998 / 4e-5
+    # (a bar of 2 % on the mean used to hide that rays leaving the back of a quad were lost at t = +inf: 0.8 % of the light)
+    ("f2_bouncing_spheres_1080p", 32, 56.0, 0.96, 1e-3),
+    ("f3_kit_world1_1080p", 32, 54.0, 0.99, 1e-3),
 ]
 
 

@@ -194,10 +194,16 @@ def test_first_hit_cornell_and_quads_volume_boundaries(ctx):
 
 def test_intervals_csg_random_rays(ctx):
     """CSG in/out intervals (count, order, entry/exit flags, t, normal, material) of the
-    reference's composition object and glass against the oracle's enumerators."""
+    reference's composition object and glass against the oracle's enumerators.  Bars: count, order,
+    flags and materials identical on all but 3 of 3000 rays (a ray grazing a leaf: the event exists in
+    one precision only); every event's t within 1e-5 |t| - or, for an event next to the ray's origin,
+    within 1e-6 of the distance from the origin to the far side of the shape, which is what float32
+    positions of that size resolve (measured: 8.2e-7 |t| at most on the composition object; on the glass
+    6.3e-5 |t| for an event at t = 0.0126, 8e-7 absolute, from an origin 7 units out) - and every
+    normal of a non-grazing event within 5e-5 (measured: 3.5e-6 at most)."""
     from raytracer_amd.renderer import NativeScene
-    for name, shape, center in (("composition", scenes._composition_object(), (0, 0, 0)),
-                                ("glass", scenes._glass(), (0, 6, 0))):
+    for name, shape, center, size in (("composition", scenes._composition_object(), (0, 0, 0), 3.0),
+                                      ("glass", scenes._glass(), (0, 6, 0), 3.0)):
         nat = NativeScene(ctx)
         sid = shape.as_impl(SceneEncoder(nat))
         nat.commit()
@@ -205,19 +211,32 @@ def test_intervals_csg_random_rays(ctx):
         oid = shape.as_impl(SceneEncoder(orc))
         rays = random_rays(3000, 11, center=center, radius=9.0, aim_radius=2.5)
         got = nat.intervals(sid, rays)
-        n_bad = 0
+        n_bad = n_events = n_grazing = 0
+        worst_t = worst_n = 0.0
         for i in range(len(rays)):
             ref = orc.enumerate(oid, rays[i, :3], rays[i, 3:], precision=ob.ORC_F64)
             ev = got[i]
             ok = len(ev) == len(ref)
             if ok:
+                d = rays[i, 3:].astype(np.float64)
+                reach = float(np.linalg.norm(rays[i, :3].astype(np.float64) - np.asarray(center))) + size
                 for a, b in zip(ev, ref):
-                    ok &= abs(float(a["t"]) - b.t) <= 1e-5 * max(abs(b.t), 10.0)
                     ok &= int(a["is_exit"]) == b.is_exit and int(a["material_offset"]) == b.material_offset
-                    ok &= max(abs(float(x) - y) for x, y in zip(a["normal"], b.normal)) <= 2e-4
+                    dt = abs(float(a["t"]) - b.t)
+                    bound = max(1e-5 * abs(b.t), 1e-6 * reach)
+                    dn = max(abs(float(x) - y) for x, y in zip(a["normal"], b.normal))
+                    grazing = abs(float(np.dot(np.asarray(b.normal), d))) < 3.5e-3
+                    n_events += 1
+                    n_grazing += int(grazing)
+                    worst_t = max(worst_t, dt / bound)
+                    ok &= dt <= bound
+                    if not grazing:
+                        worst_n = max(worst_n, dn)
+                        ok &= dn <= 5e-5
             n_bad += 0 if ok else 1
-        print(name, "interval mismatches", n_bad, "of", len(rays))
-        assert n_bad <= 3      # rays grazing a leaf: the event exists in one precision only
+        print(name, "rays", len(rays), "events", n_events, "grazing", n_grazing, "ray mismatches", n_bad,
+              "worst dt / bound %.3f" % worst_t, "worst normal difference %.3g" % worst_n)
+        assert n_bad <= 3
 
 
 def test_camera_rays_match_oracle(ctx):

@@ -45,3 +45,38 @@ def test_wyrand_matches_host_generator():
     ref = [g.next() for _ in range(16)]
     assert ob.wyrand(12345, 16) == ref
     assert [int(v) for v in wyrand_block(12345, 16)] == ref
+
+
+def test_kit_interval_algebra_gives_the_events_of_the_metal_merge():
+    """The two reference renderers evaluate a Composition differently: the Metal side merges the events of all
+    operands at once and counts depth (RenderableImpl.h:658-715), RayTracingKit folds lists of ranges from the left
+    with makeUnion / makeIntersection / makeDifference (Hittable.swift:394-526).  The oracle restates both (the Kit's
+    for scenes under the Kit's conventions); on the reference's composite shapes and on deeper nestings they must
+    enumerate the same boundary crossings: same count, order, sides, distances, materials and normals."""
+    import numpy as np
+    from common import random_rays
+    from raytracer_amd import abi, scenes
+    from raytracer_amd.scene import ColoredLambertian, Cuboid, Cylinder, Intersection, Sphere, Subtract, Transform, Union
+    m = [ColoredLambertian((0.1 * k, 0.5, 0.5)) for k in range(6)]
+    T = Transform
+    nested = Subtract(Union(Sphere((0, 0, 0), 1.0, m[0]), Cuboid(T.translate(0.2, -0.4, -0.5), (1.5, 0.8, 1.0), m[1]),
+                            Cylinder(T.translate(-0.5, -1.2, 0.3), 0.4, 2.4, m[2])),
+                      Intersection(Sphere((0.6, 0.2, 0), 0.9, m[3]), Cuboid(T.translate(0, -1, -1), (2, 2, 2), m[4])))
+    twice = Subtract(Subtract(Sphere((0, 0, 0), 1.2, m[0]), Sphere((0.5, 0, 0), 0.8, m[1])), Cylinder(T.translate(0, -2, 0), 0.3, 4.0, m[2]))
+    shapes = [("composition", scenes._composition_object(), (0, 0, 0)), ("glass", scenes._glass(), (0, 6, 0)),
+              ("nested", nested, (0, 0, 0)), ("subtract of a subtract", twice, (0, 0, 0))]
+    for name, shape, center in shapes:
+        metal, kit = ob.OracleScene(), ob.OracleScene()
+        kit.set_convention(abi.RT_CONVENTION_KIT)
+        sid, kid = shape.as_impl(SceneEncoder(metal)), shape.as_impl(SceneEncoder(kit))
+        rays = random_rays(1200, 21, center=center, radius=7.0, aim_radius=2.0)
+        n_events = 0
+        for r in rays:
+            a = metal.enumerate(sid, r[:3], r[3:], precision=ob.ORC_F64)
+            b = kit.enumerate(kid, r[:3], r[3:], precision=ob.ORC_F64)
+            assert len(a) == len(b), (name, [e.t for e in a], [e.t for e in b])
+            for x, y in zip(a, b):
+                assert x.t == y.t and x.is_exit == y.is_exit and x.material_offset == y.material_offset, (name, x.t, y.t)
+                assert list(x.normal) == list(y.normal), name
+            n_events += len(a)
+        assert n_events > 500, name
