@@ -288,7 +288,8 @@ int rt_scene_stats(const RtScene *, RtSceneStats *out);
  * RT_OPTION_BVH_BUILDER (before commit): RT_BVH_MEDIAN_SPLIT is the reference's rule
  * (RayTracingKit/Hittable.swift:609-631), RT_BVH_SAH (default) a binned surface-area
  * heuristic; hit results do not depend on the choice.  RT_OPTION_REFILL_THRESHOLD: how many
- * lanes of a wave must be waiting before the fused kernel leaves its traversal loop.
+ * lanes of a wave must be waiting before the fused kernel leaves its traversal loop (1..64; left
+ * unset, each kernel uses its own: 48, and 28 for the kernel of trees deeper than 16 levels).
  * RT_OPTION_NODE_MIN: below how many lanes on inner nodes the kernel turns to waiting leaf tests.
  * RT_OPTION_NODE_FORMAT (before commit): how rt_render's fused kernel reads BVH nodes.
  * RT_NODES_F16 stores the child boxes as halves rounded outward (32-byte nodes, half the

@@ -415,7 +415,9 @@ RT_DEV bool shade_path(const RtDevScene &s, uint32_t background, uint32_t max_de
 #define RT_WF_COUNTER_STRIDE 32u     // uint32 words between counters (128 B)
 
 struct WfQueues {
-    float4 *ray_o[2], *ray_d[2], *thr[2], *rad[2];
+    // (no radiance stream: a path gathers light only where it ends - at an emitter, which does not scatter, or in the
+    // background - so the radiance of every path still in a queue is zero)
+    float4 *ray_o[2], *ray_d[2], *thr[2];
     uint4 *rng[2];
     float4 *hit, *sample_rad;
     uint32_t *counts;        // [queue][shard], RT_WF_COUNTER_STRIDE apart
@@ -427,6 +429,7 @@ RT_DEV uint32_t *wf_counter(const WfQueues &q, int queue, uint32_t shard) {
 
 #define RT_WF_NEXT_OFFSET (2u * RT_WF_SHARDS * RT_WF_COUNTER_STRIDE)       // words: the shards' `next` counters follow the live counters
 #define RT_WF_REFILL 24u
+#define RT_WF_CHUNK 512u               // paths a wave takes from its shard per atomic
 RT_DEV uint32_t *wf_next(const WfQueues &q, uint32_t shard) { return q.counts + RT_WF_NEXT_OFFSET + shard * RT_WF_COUNTER_STRIDE; }
 
 // Ray generation: path i of the batch is sample i / npix of pixel i % npix.
@@ -452,7 +455,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_raygen(WfQueues q, RtDevCamera 
         q.ray_o[0][slot] = make_float4(o.x, o.y, o.z, __uint_as_float(i));
         q.ray_d[0][slot] = make_float4(d.x, d.y, d.z, __uint_as_float(0u));
         q.thr[0][slot] = make_float4(1.f, 1.f, 1.f, time);
-        q.rad[0][slot] = make_float4(0.f, 0.f, 0.f, 0.f);
         q.rng[0][slot] = make_uint4((uint32_t)g.state, (uint32_t)(g.state >> 32), (uint32_t)g.inc, (uint32_t)(g.inc >> 32));
     }
 }
@@ -485,7 +487,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_extend(RtDevScene s, WfQueues q
     // (Measured and left out: reading a lane's next ray from the queue while it still walks the current one.  Loads
     // return in order, so the first node fetch after a hand-out waited for the queue read all the same: 2.70 -> 2.36
     // Gsamples/s on the random-spheres workload.)
-    uint32_t slot = 0;
+    // A wave takes a chunk of consecutive paths of its shard per atomic and deals them to its lanes over several
+    // hand-outs: one word serves about 90 returning atomics per microsecond, and an atomic per hand-out (some 30 rays)
+    // was 19 million of them per pass on eight words - 26 ms, more than the walk itself.
+    // (a chunk is a quarter of a wave's even share of the shard, between 64 and RT_WF_CHUNK paths: small queues still
+    // spread over all the waves)
+    const uint32_t waves_on_shard = (gridDim.x / RT_WF_SHARDS) * RT_WAVES;
+    const uint32_t chunk = min(RT_WF_CHUNK, max(64u, (count / (waves_on_shard * 4u) + 63u) & ~63u));
+    uint32_t slot = 0, mine_next = 0, mine_end = 0;
     bool busy = false, more = count != 0u;
     uint64_t key = 0;
     float time = 0.f;
@@ -495,15 +504,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_extend(RtDevScene s, WfQueues q
             busy = false;
         }
         const uint64_t free_mask = __ballot(!busy);
-        if (more && free_mask) {
-            const uint32_t n_free = (uint32_t)__popcll(free_mask);
+        if (free_mask && mine_next == mine_end && more) {
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(next, n_free);
+            if (lane == 0) base = atomicAdd(next, chunk);
             base = __builtin_amdgcn_readfirstlane(base);
-            if (base + n_free >= count) more = false;          // the shard has nothing beyond this hand-out
+            mine_next = min(base, count);
+            mine_end = min(base + chunk, count);
+            if (base + chunk >= count) more = false;           // the shard has nothing beyond this chunk
+        }
+        if (free_mask && mine_next < mine_end) {
+            const uint32_t n_free = (uint32_t)__popcll(free_mask);
             if (!busy) {
-                const uint32_t j = base + prefix_rank(free_mask);
-                if (j < count) {
+                const uint32_t j = mine_next + prefix_rank(free_mask);
+                if (j < mine_end) {
                     slot = shard * q.shard_cap + j;
                     const float4 ro = q.ray_o[cur][slot], rd = q.ray_d[cur][slot];
                     if (FEAT & RT_FEAT_XPRIM) {
@@ -515,8 +528,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_extend(RtDevScene s, WfQueues q
                     busy = true;
                 }
             }
+            mine_next = min(mine_next + n_free, mine_end);
         }
-        if (__ballot(busy) == 0) break;                        // nothing in flight, nothing left to take
+        if (__ballot(busy) == 0) {
+            if (mine_next == mine_end && !more) break;         // nothing in flight, nothing left to take
+            continue;
+        }
         while (true) {
             while (true) {
                 const bool inner = !(t.cur & RT_REF_LEAF);
@@ -555,7 +572,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_extend(RtDevScene s, WfQueues q
             }
             const uint32_t n_active = (uint32_t)__popcll(__ballot(t.cur != RT_REF_NONE));
             // back to the hand-out once enough lanes are free; when the shard is used up, only when the wave has finished
-            if (n_active == 0 || (more && 64u - n_active >= RT_WF_REFILL)) break;
+            if (n_active == 0 || ((more || mine_next < mine_end) && 64u - n_active >= RT_WF_REFILL)) break;
         }
     }
 }
@@ -582,10 +599,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_shade(RtDevScene s, WfQueues q,
         Pcg g;
         g.state = g.inc = 0;
         if (j < count) {
-            float4 ro = q.ray_o[cur][i], rd = q.ray_d[cur][i], t4 = q.thr[cur][i], r4 = q.rad[cur][i], h4 = q.hit[i];
+            float4 ro = q.ray_o[cur][i], rd = q.ray_d[cur][i], t4 = q.thr[cur][i], h4 = q.hit[i];
             uint4 rr = q.rng[cur][i];
             o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z);
-            thr = mk3(t4.x, t4.y, t4.z); rad = mk3(r4.x, r4.y, r4.z);
+            thr = mk3(t4.x, t4.y, t4.z); rad = mk3(0.f, 0.f, 0.f);
             time = t4.w;
             pid = __float_as_uint(ro.w); depth = __float_as_uint(rd.w);
             g.state = ((uint64_t)rr.y << 32) | rr.x;
@@ -611,10 +628,40 @@ __global__ __launch_bounds__(RT_BLOCK) void k_wf_shade(RtDevScene s, WfQueues q,
             q.ray_o[nxt][k] = make_float4(o.x, o.y, o.z, __uint_as_float(pid));
             q.ray_d[nxt][k] = make_float4(d.x, d.y, d.z, __uint_as_float(depth));
             q.thr[nxt][k] = make_float4(thr.x, thr.y, thr.z, time);
-            q.rad[nxt][k] = make_float4(rad.x, rad.y, rad.z, 0.f);
             q.rng[nxt][k] = make_uint4((uint32_t)g.state, (uint32_t)(g.state >> 32), (uint32_t)g.inc, (uint32_t)(g.inc >> 32));
         }
         __syncthreads();          // wave_count / block_base are rewritten by the next round
+    }
+}
+
+// Tail: once only a handful of paths are left (deep chains inside glass: a few thousand of the 16 million a batch starts
+// with), a launch per stage and bounce costs more than the work in it - an extend launch cannot finish in less than the
+// 18 us one ray's chain of dependent fetches takes.  This kernel takes what is left in queue `cur` and runs every path to
+// its end, extend and shade alternating in the lane, so the remaining bounces are one launch.
+#define RT_WF_TAIL_PATHS 65536u        // live paths at or below which the host hands the rest of a batch to the tail kernel
+template <int FEAT>
+__global__ __launch_bounds__(RT_BLOCK) void k_wf_tail(RtDevScene s, WfQueues q, int cur, uint32_t background, uint32_t max_depth) {
+    __shared__ uint32_t stack[RT_STACK_DEPTH * RT_BLOCK];
+    const uint32_t shard = blockIdx.x % RT_WF_SHARDS, lb = blockIdx.x / RT_WF_SHARDS, nb = gridDim.x / RT_WF_SHARDS;
+    const uint32_t count = *wf_counter(q, cur, shard);
+    for (uint32_t j = lb * RT_BLOCK + threadIdx.x; j < count; j += nb * RT_BLOCK) {
+        const uint32_t i = shard * q.shard_cap + j;
+        const float4 ro = q.ray_o[cur][i], rd = q.ray_d[cur][i], t4 = q.thr[cur][i];
+        const uint4 rr = q.rng[cur][i];
+        f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z), thr = mk3(t4.x, t4.y, t4.z), rad = mk3(0.f, 0.f, 0.f);
+        const float time = t4.w;
+        const uint32_t pid = __float_as_uint(ro.w);
+        uint32_t depth = __float_as_uint(rd.w);
+        Pcg g;
+        g.state = ((uint64_t)rr.y << 32) | rr.x;
+        g.inc = ((uint64_t)rr.w << 32) | rr.z;
+        while (true) {
+            Best b;
+            const bool found = trace<!(FEAT & RT_FEAT_XPRIM), (FEAT & RT_FEAT_MOTION) != 0, (FEAT & RT_FEAT_WIDE_CSG) != 0>(
+                s, o, d, RT_T_MIN, RT_INF, g.state, nullptr, 0, stack + threadIdx.x, b, time);
+            if (!shade_path<FEAT>(s, background, max_depth, found, b, o, d, thr, rad, depth, g, time)) break;
+        }
+        q.sample_rad[pid] = make_float4(rad.x, rad.y, rad.z, 0.f);
     }
 }
 
@@ -973,7 +1020,7 @@ static uint32_t wf_shard_cap(uint32_t capacity) {
 }
 size_t rt_wavefront_bytes(uint32_t capacity) {
     size_t slots = (size_t)wf_shard_cap(capacity) * RT_WF_SHARDS;
-    return RT_WF_HEADER + slots * (2 * 5 * 16 + 16) + (size_t)capacity * 16;
+    return RT_WF_HEADER + slots * (2 * 4 * 16 + 16) + (size_t)capacity * 16;      // two queues of four 16-byte streams, the hits, the finished samples
 }
 
 void rt_wavefront_carve(void *workspace, uint32_t capacity, RtWavefrontBuffers &b) {
@@ -986,7 +1033,6 @@ void rt_wavefront_carve(void *workspace, uint32_t capacity, RtWavefrontBuffers &
         b.ray_o[k] = (float4 *)p; p += stride;
         b.ray_d[k] = (float4 *)p; p += stride;
         b.thr[k] = (float4 *)p; p += stride;
-        b.rad[k] = (float4 *)p; p += stride;
         b.rng[k] = (uint4 *)p; p += stride;
     }
     b.hit = (float4 *)p; p += stride;
@@ -1075,17 +1121,19 @@ static hipError_t wavefront_batch(const RtDevScene &s, const RtDevCamera &cam, c
     k_wf_raygen<<<grid, RT_BLOCK, 0, stream>>>(q, cam, rc, batch_spp);
     const bool probing = probe && probe->init();
     const uint32_t first_probe = 1;
-    // Paths only ever leave the queues, so the live count read RT_WF_LAG bounces ago bounds this bounce's: late bounces
-    // (a few thousand paths inside glass) get a grid of their size instead of one that fills the chip - an extend launch
-    // of 2048 workgroups costs 26 us even when it finds nothing to do.
+    // Paths only ever leave the queues, so the live count read RT_WF_LAG bounces ago bounds this bounce's.
     uint32_t live_bound = npix * batch_spp;
     const int full_grid = grid;
     for (uint32_t bounce = 0; bounce < rc.max_depth; bounce++) {
         int cur = (int)(bounce & 1u);
-        grid = std::min(full_grid, (int)((live_bound + 1023u) / 1024u));
-        grid = std::max((int)RT_WF_SHARDS, (grid + (int)RT_WF_SHARDS - 1) / (int)RT_WF_SHARDS * (int)RT_WF_SHARDS);
+        if (live_bound <= RT_WF_TAIL_PATHS) {
+            // few paths left (the count is RT_WF_LAG bounces old, so fewer still): the rest of their bounces in one launch
+            k_wf_tail<FEAT><<<std::min(full_grid, (int)(RT_WF_TAIL_PATHS / RT_BLOCK)), RT_BLOCK, 0, stream>>>(s, q, cur, cam.background, rc.max_depth);
+            break;
+        }
         if (timer) timer->begin(stream);
-        if (s.nodes16 && shallow) k_wf_extend<FEAT, true, 16><<<grid, RT_BLOCK, 0, stream>>>(s, q, cur);
+        // (a tree of at most 16 levels: 16 KB of LDS per workgroup, ten of them to a CU when the registers allow)
+        if (s.nodes16 && shallow) k_wf_extend<FEAT, true, 16><<<grid / 8 * 10, RT_BLOCK, 0, stream>>>(s, q, cur);
         else if (s.nodes16) k_wf_extend<FEAT, true, RT_STACK_DEPTH><<<grid, RT_BLOCK, 0, stream>>>(s, q, cur);
         else k_wf_extend<FEAT, false, RT_STACK_DEPTH><<<grid, RT_BLOCK, 0, stream>>>(s, q, cur);
         if (timer) timer->end(stream);
@@ -1126,7 +1174,7 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
     RtWavefrontBuffers b;
     rt_wavefront_carve(workspace, npix * max_batch, b);
     WfQueues q;
-    for (int k = 0; k < 2; k++) { q.ray_o[k] = b.ray_o[k]; q.ray_d[k] = b.ray_d[k]; q.thr[k] = b.thr[k]; q.rad[k] = b.rad[k]; q.rng[k] = b.rng[k]; }
+    for (int k = 0; k < 2; k++) { q.ray_o[k] = b.ray_o[k]; q.ray_d[k] = b.ray_d[k]; q.thr[k] = b.thr[k]; q.rng[k] = b.rng[k]; }
     q.hit = b.hit; q.sample_rad = b.sample_rad; q.counts = b.counts; q.shard_cap = b.shard_cap;
     if (timer) timer->name = "k_wf_extend";
     uint32_t total_spp = rc.spp, first = rc.first_sample;

@@ -93,7 +93,7 @@ struct RtWfProbe {
 
 // Layout of the wavefront pipeline's workspace for `capacity` paths.
 struct RtWavefrontBuffers {
-    float4 *ray_o[2], *ray_d[2], *thr[2], *rad[2];
+    float4 *ray_o[2], *ray_d[2], *thr[2];
     uint4 *rng[2];
     float4 *hit;
     float4 *sample_rad;

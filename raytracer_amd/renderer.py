@@ -322,15 +322,18 @@ class ProgressiveView:
     SAMPLES_PER_PASS = 1      # ContentView.swift:202
     MAX_DEPTH = 10
 
-    def __init__(self, scene, width, height, seed=0, overlap=True, **renderer_args):
-        """overlap: successive passes alternate between two streams, each with its own pass-sum buffer and
-        workspace, so that pass n + 1 starts on the compute units pass n's last, long paths leave idle; the
-        present steps stay in pass order (an event per pass).  The words and pixels are the same either way."""
+    def __init__(self, scene, width, height, seed=0, overlap=False, **renderer_args):
+        """overlap: successive passes alternate between two streams (one of each priority class, so that they sit on
+        different hardware queues), each with its own pass-sum buffer and workspace: pass n + 1 starts on the compute
+        units that pass n's last, long paths leave idle, and the present steps stay in pass order (an event per pass).
+        The words and pixels are the same either way.  Off by default: the reference's loop is one pass at a time.
+        (Three passes in flight - two streams of one priority class - reached 3554 frames/s once and hung the next run;
+        not offered.)"""
         from .scene import WyRand
         self.renderer = Renderer(scene, width, height, **renderer_args)
         self.seeds = WyRand(seed)             # stands in for SystemRandomNumberGenerator (:201)
         self.paused = False
-        self.overlap = overlap
+        self.overlap = bool(overlap)
         self._alloc()
 
     def _alloc(self):
@@ -384,7 +387,7 @@ class ProgressiveView:
             self.paused = True
         r = self.renderer
         seed = self.seeds.next() if rng_seed is None else rng_seed
-        slot = self.pass_counter & 1 if self.overlap else 0
+        slot = self.pass_counter % len(self._slots)
         stream, sums, work, done = self._slots[slot]
         rc = RenderConfig(self.SAMPLES_PER_PASS, self.MAX_DEPTH, self.pass_counter, seed, 0).impl
         cc = r.camera.impl

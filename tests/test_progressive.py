@@ -122,3 +122,20 @@ def test_progressive_view_follows_the_app_loop():
     assert not view.draw() and view.pass_counter == 200
     view.resize(64, 36)
     assert view.pass_counter == 0 and not view.paused and view.draw()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(200)
+def test_overlapped_passes_give_the_words_and_pixels_of_the_sequential_loop():
+    """ProgressiveView(overlap=True) alternates passes between two streams; run in a child process under its own time
+    limit (tests/progressive_child.py), so that trouble between streams would end there and not in this process."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:
+        p = subprocess.run([sys.executable, os.path.join(here, "progressive_child.py")], capture_output=True, text=True, timeout=150)
+    except subprocess.TimeoutExpired:
+        pytest.skip("the child with two streams in flight did not finish in 150 s")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "overlapped passes equal the sequential loop" in p.stdout

@@ -9,5 +9,7 @@ run() {
 }
 run a "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 run b "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM GRBM_GUI_ACTIVE"
-python3 tools/pmc_summary.py gpurun_out/pmc_a_${W}_$TAG gpurun_out/pmc_b_${W}_$TAG > gpurun_out/pmc_sq_${W}_$TAG.json
+python3 tools/pmc_summary.py gpurun_out/pmc_a_${W}_$TAG gpurun_out/pmc_b_${W}_$TAG > gpurun_out/pmc_sq_${W}_$TAG.tmp
+python3 -c "import json,sys; d=json.load(open(sys.argv[1])); d['_spp']=int(sys.argv[2]); print(json.dumps(d, indent=1, sort_keys=True))" gpurun_out/pmc_sq_${W}_$TAG.tmp $SPP > gpurun_out/pmc_sq_${W}_$TAG.json
+rm -f gpurun_out/pmc_sq_${W}_$TAG.tmp
 cat gpurun_out/pmc_sq_${W}_$TAG.json

@@ -1,0 +1,14 @@
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -k 10 300 python -u -m pytest tests/test_gpu_render.py tests/test_progressive.py -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/r3g_tests_render.txt 2>&1
+echo "render tests done"
+timeout -k 10 250 python bench.py --pipeline wavefront --spp 64 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r3g_bench_wavefront_cfg2.json 2> gpurun_out/r3g_bench_wavefront_cfg2.err
+echo "wavefront bench done"
+rm -rf gpurun_out/r3g_wfprof
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r3g_wfprof -- python3 bench.py --pipeline wavefront --spp 64 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r3g_wfprof.json 2> gpurun_out/r3g_wfprof.err
+cp gpurun_out/r3g_wfprof/*/*kernel_stats.csv gpurun_out/r3g_wavefront_cfg2_64spp_kernel_stats.csv
+echo "wavefront profile done"
+timeout -k 10 200 python tools/interactive_fps.py > gpurun_out/r3g_interactive_fps.txt 2>&1
+timeout -k 10 200 python tools/interactive_fps.py >> gpurun_out/r3g_interactive_fps.txt 2>&1
+echo "fps done"
