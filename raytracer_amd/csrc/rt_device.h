@@ -1016,6 +1016,66 @@ RT_DEV void trav_node16(const uint4 *nodes16, Trav &t, float tmin, uint32_t *sta
     }
 }
 
+// One step on the four-children node form (RtDevScene::nodes4): tests the four child boxes, goes to the nearest one
+// entered and pushes the others, farthest first.  A ray that walks a large tree pays for every node it fetches with a
+// cache line from L2, whatever the node's size: this form fetches half as many nodes for the same box tests.
+// TOP_BYTES as in trav_node16.
+template <int LDS_ENTRIES = 0, uint32_t STEP = RT_STACK_STEP, uint32_t TOP_BYTES = 0>
+RT_DEV void trav_node4(const uint4 *nodes4, Trav &t, float tmin, uint32_t *stack, const DeepStack *deep = nullptr, uint32_t top_lds = 0) {
+    const uint4 *n = (const uint4 *)((const char *)nodes4 + t.cur);
+    const bool px = t.inv_d.x >= 0.0f, py = t.inv_d.y >= 0.0f, pz = t.inv_d.z >= 0.0f;
+    const float limit = t.best.t;
+    uint4 x, y, z, r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (TOP_BYTES) {
+        const bool in_top = t.cur < TOP_BYTES;
+        if (!in_top) { x = n[0]; y = n[1]; z = n[2]; r = n[3]; }
+        if (in_top) {
+            const uint32_t addr = top_lds + t.cur;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(x), "=&v"(y), "=&v"(z), "=&v"(r) : "v"(addr) : "memory");
+        }
+    } else
+#endif
+    { x = n[0]; y = n[1]; z = n[2]; r = n[3]; }
+    // per axis: words 0, 1 the min planes of children (0,1) and (2,3), words 2, 3 their max planes
+    const v2f nxa = slab_pair(px ? x.x : x.z, t.inv_d.x, t.oid.x), nxb = slab_pair(px ? x.y : x.w, t.inv_d.x, t.oid.x);
+    const v2f fxa = slab_pair(px ? x.z : x.x, t.inv_d.x, t.oid.x), fxb = slab_pair(px ? x.w : x.y, t.inv_d.x, t.oid.x);
+    const v2f nya = slab_pair(py ? y.x : y.z, t.inv_d.y, t.oid.y), nyb = slab_pair(py ? y.y : y.w, t.inv_d.y, t.oid.y);
+    const v2f fya = slab_pair(py ? y.z : y.x, t.inv_d.y, t.oid.y), fyb = slab_pair(py ? y.w : y.y, t.inv_d.y, t.oid.y);
+    const v2f nza = slab_pair(pz ? z.x : z.z, t.inv_d.z, t.oid.z), nzb = slab_pair(pz ? z.y : z.w, t.inv_d.z, t.oid.z);
+    const v2f fza = slab_pair(pz ? z.z : z.x, t.inv_d.z, t.oid.z), fzb = slab_pair(pz ? z.w : z.y, t.inv_d.z, t.oid.z);
+    const float t0 = fmaxf(fmaxf(nxa.x, nya.x), fmaxf(nza.x, tmin)), t1 = fmaxf(fmaxf(nxa.y, nya.y), fmaxf(nza.y, tmin));
+    const float t2 = fmaxf(fmaxf(nxb.x, nyb.x), fmaxf(nzb.x, tmin)), t3 = fmaxf(fmaxf(nxb.y, nyb.y), fmaxf(nzb.y, tmin));
+    const float e0 = fminf(fminf(fxa.x, fya.x), min_raw(fza.x, limit)), e1 = fminf(fminf(fxa.y, fya.y), min_raw(fza.y, limit));
+    const float e2 = fminf(fminf(fxb.x, fyb.x), min_raw(fzb.x, limit)), e3 = fminf(fminf(fxb.y, fyb.y), min_raw(fzb.y, limit));
+    // Sort keys: the entry distance (not below tmin > 0, so its bits order as the floats do) with the child's number
+    // in the two lowest bits; a child that is not entered sorts last.
+    const uint32_t MISS = 0xFFFFFFFFu;
+    uint32_t k0 = t0 <= e0 ? (__float_as_uint(t0) & ~3u) : MISS, k1 = t1 <= e1 ? (__float_as_uint(t1) & ~3u) | 1u : MISS;
+    uint32_t k2 = t2 <= e2 ? (__float_as_uint(t2) & ~3u) | 2u : MISS, k3 = t3 <= e3 ? (__float_as_uint(t3) & ~3u) | 3u : MISS;
+    uint32_t lo, hi;
+#define RT_ORDER(a, b) lo = min(a, b); hi = max(a, b); a = lo; b = hi
+    RT_ORDER(k0, k1); RT_ORDER(k2, k3); RT_ORDER(k0, k2); RT_ORDER(k1, k3); RT_ORDER(k1, k2);
+#undef RT_ORDER
+#define RT_CHILD(k) (((k) & 2u) ? (((k) & 1u) ? r.w : r.z) : (((k) & 1u) ? r.y : r.x))
+    if (k0 == MISS) {
+        trav_pop<LDS_ENTRIES, STEP>(t, stack, deep);
+        return;
+    }
+    if (k1 != MISS) {
+        if (k2 != MISS) {
+            if (k3 != MISS) { stack_put<LDS_ENTRIES, STEP>(deep, t.sp, RT_CHILD(k3)); t.sp += STEP; }
+            stack_put<LDS_ENTRIES, STEP>(deep, t.sp, RT_CHILD(k2));
+            t.sp += STEP;
+        }
+        stack_put<LDS_ENTRIES, STEP>(deep, t.sp, RT_CHILD(k1));
+        t.sp += STEP;
+    }
+    t.cur = RT_CHILD(k0);
+#undef RT_CHILD
+}
+
 // Runs one ray to completion (parity kernels and the wavefront extend stage).
 template <bool SIMPLE, bool MOTION = false, bool WIDE = false>
 RT_DEV bool trace(const RtDevScene &s, f3 o, f3 d, float tmin, float tmax, uint64_t volume_key,

@@ -366,6 +366,97 @@ std::vector<uint32_t> pack_nodes16(const std::vector<float> &nodes) {
     return out;
 }
 
+// The four-children node form (RtDevScene::nodes4) of a binary tree: every node takes the children of its two children
+// in their place (a leaf child stays as it is), so the tree has half the levels, the same boxes and the same leaves.
+// The `top_n` nodes with the largest boxes come first in the array (as Builder::hoist_top does for the binary form),
+// the others in pre-order.  root4: the root's reference; depth4: levels of inner nodes.
+std::vector<uint32_t> pack_nodes4(const std::vector<float> &nodes, uint32_t root, size_t top_n, uint32_t &root4, uint32_t &depth4) {
+    struct Wide { float box[4][6]; uint32_t ref[4]; };
+    depth4 = 0;
+    if (root & RT_REF_LEAF) { root4 = root; return {}; }
+    std::vector<Wide> wide;
+    auto child_ref = [&](uint32_t node, int k) { uint32_t r; memcpy(&r, nodes.data() + 16 * (size_t)node + 12 + k, 4); return r; };
+    // pre-order, without recursion: (binary node, index of its wide node, level)
+    struct Todo { uint32_t node, index, level; };
+    std::vector<Todo> todo;
+    wide.emplace_back();
+    todo.push_back({root, 0u, 1u});
+    while (!todo.empty()) {
+        const Todo cur = todo.back();
+        todo.pop_back();
+        depth4 = std::max(depth4, cur.level);
+        const float *picked_box[4];
+        uint32_t picked_ref[4];
+        int n = 0;
+        for (int k = 0; k < 2; k++) {
+            const uint32_t r = child_ref(cur.node, k);
+            if (r == RT_REF_NONE) continue;
+            if (r & RT_REF_LEAF) { picked_box[n] = nodes.data() + 16 * (size_t)cur.node + 6 * k; picked_ref[n++] = r; continue; }
+            for (int j = 0; j < 2; j++) {
+                const uint32_t rr = child_ref(r, j);
+                if (rr == RT_REF_NONE) continue;
+                picked_box[n] = nodes.data() + 16 * (size_t)r + 6 * j;
+                picked_ref[n++] = rr;
+            }
+        }
+        uint32_t inner_index[4];
+        for (int c = 0; c < n; c++)
+            if (!(picked_ref[c] & RT_REF_LEAF)) { inner_index[c] = (uint32_t)wide.size(); wide.emplace_back(); }
+        Wide &w = wide[cur.index];
+        for (int c = 0; c < 4; c++) {
+            if (c < n) {
+                memcpy(w.box[c], picked_box[c], 24);
+                w.ref[c] = (picked_ref[c] & RT_REF_LEAF) ? picked_ref[c] : inner_index[c];
+            } else {
+                for (int a = 0; a < 3; a++) { w.box[c][2 * a] = INFINITY; w.box[c][2 * a + 1] = -INFINITY; }
+                w.ref[c] = RT_REF_NONE;
+            }
+        }
+        for (int c = n - 1; c >= 0; c--)
+            if (!(picked_ref[c] & RT_REF_LEAF)) todo.push_back({picked_ref[c], inner_index[c], cur.level + 1u});
+    }
+    // the nodes with the largest boxes first
+    const size_t count = wide.size();
+    std::vector<uint32_t> new_index(count, UINT32_MAX);
+    {
+        auto area = [](const float *b) {
+            const float dx = b[1] - b[0], dy = b[3] - b[2], dz = b[5] - b[4];
+            if (!(dx >= 0.f) || !(dy >= 0.f) || !(dz >= 0.f)) return 0.f;
+            const float a = dx * dy + dy * dz + dz * dx;
+            return std::isfinite(a) ? a : 3.0e38f;
+        };
+        std::vector<std::pair<float, uint32_t>> heap;
+        auto less = [](const std::pair<float, uint32_t> &a, const std::pair<float, uint32_t> &b) {
+            return a.first < b.first || (a.first == b.first && a.second > b.second);
+        };
+        heap.push_back({3.4e38f, 0u});
+        uint32_t next = 0;
+        while (!heap.empty() && next < top_n) {
+            std::pop_heap(heap.begin(), heap.end(), less);
+            const uint32_t node = heap.back().second;
+            heap.pop_back();
+            new_index[node] = next++;
+            for (int c = 0; c < 4; c++)
+                if (!(wide[node].ref[c] & RT_REF_LEAF)) { heap.push_back({area(wide[node].box[c]), wide[node].ref[c]}); std::push_heap(heap.begin(), heap.end(), less); }
+        }
+        for (size_t i = 0; i < count; i++)
+            if (new_index[i] == UINT32_MAX) new_index[i] = next++;
+    }
+    std::vector<uint32_t> out(16 * count);
+    for (size_t i = 0; i < count; i++) {
+        const Wide &w = wide[i];
+        uint32_t *o = out.data() + 16 * (size_t)new_index[i];
+        for (int a = 0; a < 3; a++)
+            for (int pair = 0; pair < 2; pair++) {
+                o[4 * a + pair] = (uint32_t)half_toward(w.box[2 * pair][2 * a], false) | ((uint32_t)half_toward(w.box[2 * pair + 1][2 * a], false) << 16);
+                o[4 * a + 2 + pair] = (uint32_t)half_toward(w.box[2 * pair][2 * a + 1], true) | ((uint32_t)half_toward(w.box[2 * pair + 1][2 * a + 1], true) << 16);
+            }
+        for (int c = 0; c < 4; c++) o[12 + c] = (w.ref[c] & RT_REF_LEAF) ? w.ref[c] : new_index[w.ref[c]] * 64u;
+    }
+    root4 = new_index[0] * 64u;
+    return out;
+}
+
 struct Builder {
     std::vector<BuildItem> items;
     std::vector<float> nodes;      // 16 floats per node
@@ -1267,6 +1358,18 @@ static int scene_commit(RtScene *sc) {
         if (sc->use_nodes16) {
             std::vector<uint32_t> n16 = pack_nodes16(bld.nodes);
             if ((rc = upload(sc, n16, &d.nodes16)) < 0) return rc;
+            // a deep tree of plain spheres is walked in its four-children form; its stack holds at most three entries
+            // per level
+            if ((feat & 7u) == 0 && bld.max_depth > 16 && !(root & RT_REF_LEAF)) {
+                uint32_t root4 = RT_REF_NONE, depth4 = 0;
+                std::vector<uint32_t> n4 = pack_nodes4(bld.nodes, root, RT_TOP_NODES_MAX / 2, root4, depth4);
+                if (getenv("RT_SHOW_OCCUPANCY")) fprintf(stderr, "four-children form: %zu nodes, %u levels (binary: %zu nodes, %u levels)\n", n4.size() / 16, depth4, bld.nodes.size() / 16, (unsigned)bld.max_depth);
+                if (3u * depth4 <= RT_WIDE_STACK_DEPTH && n4.size() / 16 < (1u << 25)) {
+                    if ((rc = upload(sc, n4, &d.nodes4)) < 0) return rc;
+                    d.root4 = root4;
+                    d.n_nodes4 = (uint32_t)(n4.size() / 16);
+                }
+            }
         }
     }
     if ((rc = upload(sc, spheres, &d.spheres)) < 0) return rc;

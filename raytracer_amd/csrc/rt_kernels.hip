@@ -734,7 +734,8 @@ __global__ void k_fused_setup(uint32_t *workspace, RtDevCamera cam) {
 // BLOCK: threads per workgroup.  TOP: nodes at the head of the 32-byte node array that every workgroup also keeps in
 // LDS (the builder of a deep tree puts the nodes with the largest boxes there); a larger workgroup shares one copy
 // among more waves.
-template <int FEAT, bool PROF, int STACK, int WPS, bool NODE16, bool DEEP = false, bool LIST = false, int BLOCK = RT_BLOCK, int TOP = 0>
+// ARITY 4: the tree is read in its four-children form (RtDevScene::nodes4; TOP then counts 32-byte halves of its nodes).
+template <int FEAT, bool PROF, int STACK, int WPS, bool NODE16, bool DEEP = false, bool LIST = false, int BLOCK = RT_BLOCK, int TOP = 0, int ARITY = 2>
 __global__ __launch_bounds__(BLOCK, WPS) void k_fused(RtDevScene s, const RtDevCamera *camp, uint32_t background, RtDevRender rc, float *accum,
                                                      uint32_t *counter, uint32_t n_items, uint32_t tiles_x,
                                                      uint32_t n_tiles, uint32_t chunk_spp, uint32_t knobs, uint32_t heavy_and_counters) {
@@ -750,8 +751,9 @@ __global__ __launch_bounds__(BLOCK, WPS) void k_fused(RtDevScene s, const RtDevC
     __shared__ __attribute__((aligned(16))) uint4 top_nodes[TOP ? 2 * TOP : 1];
     uint32_t top_lds = 0;
     if (TOP) {
-        const uint32_t n_top = min((uint32_t)TOP, s.n_nodes) * 2u;
-        for (uint32_t i = threadIdx.x; i < 2u * TOP; i += BLOCK) top_nodes[i] = i < n_top ? ((const uint4 *)s.nodes16)[i] : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t n_top = ARITY == 4 ? min(2u * TOP, s.n_nodes4 * 4u) : min((uint32_t)TOP, s.n_nodes) * 2u;
+        const uint4 *head = (const uint4 *)(ARITY == 4 ? s.nodes4 : s.nodes16);
+        for (uint32_t i = threadIdx.x; i < 2u * TOP; i += BLOCK) top_nodes[i] = i < n_top ? head[i] : make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
         top_lds = lds_address((const uint32_t *)top_nodes);
     }
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void k_fused(RtDevScene s, const RtDevC
     float *acc = tile_acc[threadIdx.x >> 6];
     const uint64_t seed = ((uint64_t)rc.seed_hi << 32) | rc.seed_lo;
     const float4 *nodes = (const float4 *)s.nodes;
-    const uint4 *nodes16 = (const uint4 *)s.nodes16;
+    const uint4 *nodes16 = (const uint4 *)(ARITY == 4 ? s.nodes4 : s.nodes16);
     unsigned long long pc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // {execs, lanes, cycles} x {shade, raygen, node, leaf}, flops of the object tests, box tests of the list form
     unsigned long long stamp = 0;
 #define RT_PROF_BEGIN() do { if (PROF) stamp = __builtin_amdgcn_s_memtime(); } while (0)
@@ -902,7 +904,7 @@ __global__ __launch_bounds__(BLOCK, WPS) void k_fused(RtDevScene s, const RtDevC
         if (start) {
             key = g.state;
             // the 32-byte node form walks byte offsets
-            trav_begin(t, (NODE16 && !(s.root & RT_REF_LEAF)) ? s.root * 32u : s.root, o, d, RT_INF, stack);
+            trav_begin(t, ARITY == 4 ? s.root4 : (NODE16 && !(s.root & RT_REF_LEAF)) ? s.root * 32u : s.root, o, d, RT_INF, stack);
         }
         const uint32_t n_paths = (uint32_t)__popcll(__ballot(has_path));
         if (n_paths == 0) {
@@ -967,7 +969,8 @@ __global__ __launch_bounds__(BLOCK, WPS) void k_fused(RtDevScene s, const RtDevC
                 if ((n_inner < node_min && n_ready) || n_ready >= leaf_max) break;
                 RT_PROF_BEGIN();
                 if (inner) {
-                    if (NODE16) trav_node16<LDS_ENTRIES, STEP, TOP * 32u>(nodes16, t, RT_T_MIN, stack, deep, top_lds);
+                    if (ARITY == 4) trav_node4<LDS_ENTRIES, STEP, TOP * 32u>(nodes16, t, RT_T_MIN, stack, deep, top_lds);
+                    else if (NODE16) trav_node16<LDS_ENTRIES, STEP, TOP * 32u>(nodes16, t, RT_T_MIN, stack, deep, top_lds);
                     else trav_node<LDS_ENTRIES, STEP>(nodes, t, RT_T_MIN, stack, deep);
                 }
                 RT_PROF_END(2, inner);
@@ -976,7 +979,8 @@ __global__ __launch_bounds__(BLOCK, WPS) void k_fused(RtDevScene s, const RtDevC
                     RT_PROF_BEGIN();
                     const bool inner2 = !(t.cur & RT_REF_LEAF);
                     if (inner2) {
-                        if (NODE16) trav_node16<LDS_ENTRIES, STEP, TOP * 32u>(nodes16, t, RT_T_MIN, stack, deep, top_lds);
+                        if (ARITY == 4) trav_node4<LDS_ENTRIES, STEP, TOP * 32u>(nodes16, t, RT_T_MIN, stack, deep, top_lds);
+                        else if (NODE16) trav_node16<LDS_ENTRIES, STEP, TOP * 32u>(nodes16, t, RT_T_MIN, stack, deep, top_lds);
                         else trav_node<LDS_ENTRIES, STEP>(nodes, t, RT_T_MIN, stack, deep);
                     }
                     RT_PROF_END(2, inner2);
@@ -1104,6 +1108,10 @@ hipError_t rt_launch_progressive_present(const float *pass_sum, uint32_t spp, ui
 
 // Header (item counters, diagnostics, camera) + the deep-stack columns of the largest grid.
 size_t rt_fused_workspace_bytes(int cus) {
+    return RT_FUSED_DEEP_OFFSET + (size_t)cus * 8u * RT_BLOCK * (RT_WIDE_STACK_DEPTH - 16) * 4u;
+}
+// The least a deep tree needs for the kernels that keep 16 stack entries per lane in LDS: columns for the binary form.
+static size_t fused_workspace_bytes_binary(int cus) {
     return RT_FUSED_DEEP_OFFSET + (size_t)cus * 8u * RT_BLOCK * (RT_STACK_DEPTH - 16) * 4u;
 }
 
@@ -1200,7 +1208,7 @@ hipError_t rt_render_wavefront(const RtDevScene &s, uint32_t feat, const RtDevCa
     return hipSuccess;
 }
 
-template <int FEAT, int STACK, int WPS, bool NODE16, bool DEEP = false, bool LIST = false, int BLOCK = RT_BLOCK, int TOP = 0>
+template <int FEAT, int STACK, int WPS, bool NODE16, bool DEEP = false, bool LIST = false, int BLOCK = RT_BLOCK, int TOP = 0, int ARITY = 2>
 static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, const RtDevRender &rc, float *accum,
                                uint32_t *counter, uint32_t knobs, uint32_t knobs2, hipStream_t stream, RtKernelTimer *timer, int cus,
                                bool prepare_only) {
@@ -1219,12 +1227,12 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     (void)hipGetDevice(&dev);
     int occ = (dev >= 0 && dev < 64) ? occ_of_device[dev].load(std::memory_order_relaxed) : 0;
     if (occ < 1) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS, NODE16, DEEP, LIST, BLOCK, TOP>, BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused<FEAT, false, STACK, WPS, NODE16, DEEP, LIST, BLOCK, TOP, ARITY>, BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
         if (dev >= 0 && dev < 64) occ_of_device[dev].store(occ, std::memory_order_relaxed);
     }
     if (prepare_only) return hipSuccess;
     static const bool show_occupancy = getenv("RT_SHOW_OCCUPANCY") != nullptr;       // diagnostic: what the runtime answered
-    if (show_occupancy) fprintf(stderr, "k_fused<feat %d, stack %d, wps %d, block %d, top %d>: %d workgroups per CU\n", FEAT, STACK, WPS, BLOCK, TOP, occ);
+    if (show_occupancy) fprintf(stderr, "k_fused<feat %d, stack %d, wps %d, block %d, top %d, arity %d>: %d workgroups per CU\n", FEAT, STACK, WPS, BLOCK, TOP, ARITY, occ);
     if (DEEP) occ = std::min(occ, 2048 / BLOCK);        // the deep-stack columns are sized for 2048 threads per CU
     int grid = cus * occ;
     // Work items = tiles x sample chunks.  Large chunks leave the waves finishing at different
@@ -1255,9 +1263,9 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     const RtDevCamera *camp = (const RtDevCamera *)((const char *)counter + RT_FUSED_CAMERA_OFFSET);
     if (timer) timer->begin(stream);
     if (prof)
-        k_fused<FEAT, true, STACK, WPS, NODE16, DEEP, LIST, BLOCK, TOP><<<grid, BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u) | (counters_log2 << 8));
+        k_fused<FEAT, true, STACK, WPS, NODE16, DEEP, LIST, BLOCK, TOP, ARITY><<<grid, BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u) | (counters_log2 << 8));
     else
-        k_fused<FEAT, false, STACK, WPS, NODE16, DEEP, LIST, BLOCK, TOP><<<grid, BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u) | (counters_log2 << 8));
+        k_fused<FEAT, false, STACK, WPS, NODE16, DEEP, LIST, BLOCK, TOP, ARITY><<<grid, BLOCK, 0, stream>>>(s, camp, cam.background, rc, accum, counter, n_items, tiles_x, n_tiles, chunk_spp, knobs, (knobs2 & 127u) | (counters_log2 << 8));
     if (timer) timer->end(stream);
     return hipGetLastError();
 }
@@ -1296,13 +1304,18 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
         if (bvh_depth <= 16) return RT_FUSED(0, 16, RT_WPS0);
         // a deep tree (a million spheres) waits on memory, not on the ALUs: 8 waves per SIMD with
         // the rare deep stack entries in global memory beat 5 waves with the whole stack in LDS
-        if (workspace_bytes >= rt_fused_workspace_bytes(cus) || prepare_only) {
+        if (workspace_bytes >= fused_workspace_bytes_binary(cus) || prepare_only) {
             // With 32-byte nodes: 512-thread workgroups that keep the RT_TOP_NODES nodes at the head of the node array
             // (the largest boxes: the builder of a deep tree puts them there) in LDS, 6 waves per SIMD.  RT_DEEP_PLAIN=1
             // in the environment runs the kernel without the LDS copy (7 waves per SIMD), for comparison.
             static const bool plain = getenv("RT_DEEP_PLAIN") != nullptr;
             hipError_t e;
-            if (n16 && !plain) e = fused_launch<0, 16, 6, true, true, false, 512, RT_TOP_NODES>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
+            static const bool binary = getenv("RT_DEEP_BINARY") != nullptr;      // for comparison: the 32-byte two-children nodes
+            if (n16 && !plain && !binary && s.nodes4 && (workspace_bytes >= rt_fused_workspace_bytes(cus) || prepare_only)) {
+                e = fused_launch<0, 16, 6, true, true, false, 512, RT_TOP_NODES, 4>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
+                // (a caller with the smaller workspace - the static scratch array - renders the binary form: prepare that too)
+                if (prepare_only) (void)fused_launch<0, 16, 6, true, true, false, 512, RT_TOP_NODES>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, true);
+            } else if (n16 && !plain) e = fused_launch<0, 16, 6, true, true, false, 512, RT_TOP_NODES>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
             else if (n16) e = fused_launch<0, 16, RT_WPS_DEEP, true, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
             else e = fused_launch<0, 16, RT_WPS_DEEP, false, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
             if (!prepare_only) return e;

@@ -39,6 +39,9 @@ enum RtPrimKind : uint32_t {
 // stacks, the builder's depth limit, the commit-time depth check and the deep-stack columns of
 // the fused workspace all follow this one definition.
 #define RT_STACK_DEPTH 24
+// The four-children form of a tree of RT_STACK_DEPTH levels has half the levels and leaves at most three entries on the
+// stack per level: the deep-stack columns of the fused workspace are sized for this many entries per lane.
+#define RT_WIDE_STACK_DEPTH (3 * ((RT_STACK_DEPTH + 1) / 2))
 #define RT_BLOCK 256             // threads per workgroup of every traversal kernel
 #define RT_TOP_NODES_MAX 1024    // nodes the builder of a deep tree moves to the head of the node array, largest boxes first
 #define RT_LINEAR_MAX 16         // scenes up to this many objects are rendered without a tree
@@ -141,6 +144,13 @@ struct RtDevScene {
     uint32_t root;                 // child reference of the root (RT_REF_NONE for an empty scene)
     uint32_t n_nodes;
     uint32_t kit_convention;       // 1: RayTracingKit's texture coordinates and metal rule (RT_CONVENTION_KIT)
+    uint32_t root4;                // the root's reference in nodes4 (byte offset or leaf)
+    // A deep tree of spheres also has its nodes in a four-children form, two levels of the binary tree per node (same
+    // boxes, same leaves): 64 bytes = per axis the four children's min planes and max planes as halves rounded outward
+    // (children 0,1 | 2,3 | 0,1 | 2,3), then four refs (an inner child as its byte offset in this array; an absent
+    // child is RT_REF_NONE behind the empty box).  nullptr when the scene has none.
+    const uint32_t *nodes4;
+    uint32_t n_nodes4;
     uint32_t pad;
 };
 
