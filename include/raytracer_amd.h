@@ -176,6 +176,8 @@ typedef struct {
     uint32_t n_spheres, n_cylinders, n_cuboids, n_quads, n_csg, n_cdv;
     uint32_t n_materials, n_textures, n_perlin;
     uint64_t device_bytes;
+    uint32_t n_wide_nodes;    /* nodes of the four-children form a deep tree of spheres is rendered from (0: the scene has none) */
+    uint32_t reserved;
 } RtSceneStats;
 
 enum RtCsgOp { RT_CSG_UNION = 0, RT_CSG_INTERSECTION = 1, RT_CSG_SUBTRACT = 2 };

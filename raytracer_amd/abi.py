@@ -203,7 +203,7 @@ class RtSceneStats(C.Structure):
                 ("n_spheres", C.c_uint32), ("n_cylinders", C.c_uint32), ("n_cuboids", C.c_uint32),
                 ("n_quads", C.c_uint32), ("n_csg", C.c_uint32), ("n_cdv", C.c_uint32),
                 ("n_materials", C.c_uint32), ("n_textures", C.c_uint32), ("n_perlin", C.c_uint32),
-                ("device_bytes", C.c_uint64)]
+                ("device_bytes", C.c_uint64), ("n_wide_nodes", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 assert C.sizeof(RtHit) == 48 and C.sizeof(RtEvent) == 48

@@ -1049,31 +1049,30 @@ RT_DEV void trav_node4(const uint4 *nodes4, Trav &t, float tmin, uint32_t *stack
     const float t2 = fmaxf(fmaxf(nxb.x, nyb.x), fmaxf(nzb.x, tmin)), t3 = fmaxf(fmaxf(nxb.y, nyb.y), fmaxf(nzb.y, tmin));
     const float e0 = fminf(fminf(fxa.x, fya.x), min_raw(fza.x, limit)), e1 = fminf(fminf(fxa.y, fya.y), min_raw(fza.y, limit));
     const float e2 = fminf(fminf(fxb.x, fyb.x), min_raw(fzb.x, limit)), e3 = fminf(fminf(fxb.y, fyb.y), min_raw(fzb.y, limit));
-    // Sort keys: the entry distance (not below tmin > 0, so its bits order as the floats do) with the child's number
-    // in the two lowest bits; a child that is not entered sorts last.
+    // The children entered, nearest first: (entry distance, ref) pairs through a five-exchange network.  The distance is
+    // not below tmin > 0, so its bits order as the floats do; a child that is not entered sorts last.
     const uint32_t MISS = 0xFFFFFFFFu;
-    uint32_t k0 = t0 <= e0 ? (__float_as_uint(t0) & ~3u) : MISS, k1 = t1 <= e1 ? (__float_as_uint(t1) & ~3u) | 1u : MISS;
-    uint32_t k2 = t2 <= e2 ? (__float_as_uint(t2) & ~3u) | 2u : MISS, k3 = t3 <= e3 ? (__float_as_uint(t3) & ~3u) | 3u : MISS;
-    uint32_t lo, hi;
-#define RT_ORDER(a, b) lo = min(a, b); hi = max(a, b); a = lo; b = hi
-    RT_ORDER(k0, k1); RT_ORDER(k2, k3); RT_ORDER(k0, k2); RT_ORDER(k1, k3); RT_ORDER(k1, k2);
+    uint32_t k0 = t0 <= e0 ? __float_as_uint(t0) : MISS, k1 = t1 <= e1 ? __float_as_uint(t1) : MISS;
+    uint32_t k2 = t2 <= e2 ? __float_as_uint(t2) : MISS, k3 = t3 <= e3 ? __float_as_uint(t3) : MISS;
+    uint32_t r0 = r.x, r1 = r.y, r2 = r.z, r3 = r.w;
+#define RT_ORDER(ka, ra, kb, rb) { const bool sw = kb < ka; const uint32_t k_lo = sw ? kb : ka, k_hi = sw ? ka : kb, r_lo = sw ? rb : ra, r_hi = sw ? ra : rb; \
+                                   ka = k_lo; kb = k_hi; ra = r_lo; rb = r_hi; }
+    RT_ORDER(k0, r0, k1, r1) RT_ORDER(k2, r2, k3, r3) RT_ORDER(k0, r0, k2, r2) RT_ORDER(k1, r1, k3, r3) RT_ORDER(k1, r1, k2, r2)
 #undef RT_ORDER
-#define RT_CHILD(k) (((k) & 2u) ? (((k) & 1u) ? r.w : r.z) : (((k) & 1u) ? r.y : r.x))
     if (k0 == MISS) {
         trav_pop<LDS_ENTRIES, STEP>(t, stack, deep);
         return;
     }
     if (k1 != MISS) {
         if (k2 != MISS) {
-            if (k3 != MISS) { stack_put<LDS_ENTRIES, STEP>(deep, t.sp, RT_CHILD(k3)); t.sp += STEP; }
-            stack_put<LDS_ENTRIES, STEP>(deep, t.sp, RT_CHILD(k2));
+            if (k3 != MISS) { stack_put<LDS_ENTRIES, STEP>(deep, t.sp, r3); t.sp += STEP; }
+            stack_put<LDS_ENTRIES, STEP>(deep, t.sp, r2);
             t.sp += STEP;
         }
-        stack_put<LDS_ENTRIES, STEP>(deep, t.sp, RT_CHILD(k1));
+        stack_put<LDS_ENTRIES, STEP>(deep, t.sp, r1);
         t.sp += STEP;
     }
-    t.cur = RT_CHILD(k0);
-#undef RT_CHILD
+    t.cur = r0;
 }
 
 // Runs one ray to completion (parity kernels and the wavefront extend stage).

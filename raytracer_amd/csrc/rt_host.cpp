@@ -1421,6 +1421,7 @@ static int scene_commit(RtScene *sc) {
     RtSceneStats &st = sc->stats;
     st.n_objects = (uint32_t)bld.items.size();
     st.n_nodes = d.n_nodes;
+    st.n_wide_nodes = d.n_nodes4;
     st.bvh_depth = bld.max_depth;
     st.n_spheres = (uint32_t)(spheres.size() / 4);
     for (const HostShape &s : sc->shapes) {
@@ -1580,8 +1581,8 @@ namespace {
 // spheres move: the change of frame makes their test dearer); tests
 // of cylinders, boxes, CSG shapes and volumes cost several node steps and wait for fuller waves.
 uint32_t fused_knobs(const RtScene *sc, const RtDevCamera &cam) {
-    const uint32_t node_min = sc->node_min >= 0 ? (uint32_t)sc->node_min : 8u;
-    // refill = 0 goes through as it is: the launcher puts the chosen kernel's default in
+    // refill = 0 and node_min = 255 stand for "not set": the launcher puts the chosen kernel's defaults in
+    const uint32_t node_min = sc->node_min >= 0 ? (uint32_t)std::min(sc->node_min, 254) : 255u;
     return sc->refill | (node_min << 8) | (sc->profile_phases ? 0x10000u : 0u) | (sc->use_nodes16 ? 0x20000u : 0u) |
            ((cam.defocus ? 16u : 0u) << 18) | (((sc->feat & RT_FEAT_XPRIM) ? 65u : ((sc->feat & RT_FEAT_MOTION) ? 20u : 12u)) << 25);
 }

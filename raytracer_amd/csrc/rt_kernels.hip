@@ -40,6 +40,12 @@
 #ifndef RT_WPS_MOVING_SPHERES
 #define RT_WPS_MOVING_SPHERES 6   // ... of the spheres-and-moving-spheres kernel
 #endif
+#ifndef RT_WIDE_REFILL
+#define RT_WIDE_REFILL 24u
+#endif
+#ifndef RT_WIDE_NODE_MIN
+#define RT_WIDE_NODE_MIN 40u
+#endif
 #ifndef RT_TOP_NODES
 #define RT_TOP_NODES 448       // nodes of a deep tree's head kept in LDS by its kernel (14 KB next to a 512-thread workgroup's 32-KB stack: three workgroups per CU)
 #endif
@@ -1256,7 +1262,10 @@ static hipError_t fused_launch(const RtDevScene &s, const RtDevCamera &cam, cons
     // refill threshold left at 0 by the caller: 48 finished or free lanes before a wave leaves its traversal loop; the
     // kernel that reads the top of the tree from LDS does better with fuller waves (28: +12 % over 48 there, where the
     // plain deep-tree kernel loses 2 % with 32)
-    if ((knobs & 255u) == 0u) knobs |= TOP ? 28u : 48u;
+    if ((knobs & 255u) == 0u) knobs |= ARITY == 4 ? RT_WIDE_REFILL : TOP ? 28u : 48u;
+    // node_min left at 255: a wave goes on with node steps while 8 lanes stand on inner nodes; the four-children step is
+    // three times as long and is not run for so few
+    if (((knobs >> 8) & 255u) == 255u) knobs = (knobs & ~0xFF00u) | ((ARITY == 4 ? RT_WIDE_NODE_MIN : 8u) << 8);
     k_fused_setup<<<1, 256, 0, stream>>>(counter, cam);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1302,19 +1311,19 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
     switch (feat & 7u) {
     case 0:
         if (bvh_depth <= 16) return RT_FUSED(0, 16, RT_WPS0);
-        // a deep tree (a million spheres) waits on memory, not on the ALUs: 8 waves per SIMD with
+        // a deep tree (a million spheres) waits on memory, not on the ALUs: many waves per SIMD with
         // the rare deep stack entries in global memory beat 5 waves with the whole stack in LDS
         if (workspace_bytes >= fused_workspace_bytes_binary(cus) || prepare_only) {
-            // With 32-byte nodes: 512-thread workgroups that keep the RT_TOP_NODES nodes at the head of the node array
-            // (the largest boxes: the builder of a deep tree puts them there) in LDS, 6 waves per SIMD.  RT_DEEP_PLAIN=1
-            // in the environment runs the kernel without the LDS copy (7 waves per SIMD), for comparison.
+            // With half-precision nodes: 512-thread workgroups that keep the head of the node array (the largest boxes:
+            // the builder of a deep tree puts them there) in LDS, 6 waves per SIMD, walking the four-children form
+            // (1.46 Gsamples/s on a million spheres at 4K).  For comparison, from the environment: RT_DEEP_BINARY=1 walks
+            // the 32-byte two-children nodes in the same way (0.98), RT_DEEP_PLAIN=1 those without the LDS copy, 7 waves
+            // per SIMD (0.93).
             static const bool plain = getenv("RT_DEEP_PLAIN") != nullptr;
+            static const bool binary = getenv("RT_DEEP_BINARY") != nullptr;
             hipError_t e;
-            static const bool binary = getenv("RT_DEEP_BINARY") != nullptr;      // for comparison: the 32-byte two-children nodes
             if (n16 && !plain && !binary && s.nodes4 && (workspace_bytes >= rt_fused_workspace_bytes(cus) || prepare_only)) {
                 e = fused_launch<0, 16, 6, true, true, false, 512, RT_TOP_NODES, 4>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
-                // (a caller with the smaller workspace - the static scratch array - renders the binary form: prepare that too)
-                if (prepare_only) (void)fused_launch<0, 16, 6, true, true, false, 512, RT_TOP_NODES>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, true);
             } else if (n16 && !plain) e = fused_launch<0, 16, 6, true, true, false, 512, RT_TOP_NODES>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
             else if (n16) e = fused_launch<0, 16, RT_WPS_DEEP, true, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
             else e = fused_launch<0, 16, RT_WPS_DEEP, false, true>(s, cam, rc, accum, counter, knobs, knobs2, stream, timer, cus, prepare_only);
@@ -1340,7 +1349,7 @@ hipError_t rt_render_fused(const RtDevScene &s, uint32_t feat, uint32_t bvh_dept
 // until the process ends.  `scratch` is a host-side stand-in for the symbol, never a device
 // address: the address of each device's copy comes from hipGetSymbolAddress with that device
 // current (rt_static_scratch_init), and only that pointer is handed to kernels and memsets.
-#define RT_STATIC_SCRATCH_BYTES (RT_FUSED_DEEP_OFFSET + (size_t)RT_STATIC_MAX_CUS * 8u * RT_BLOCK * (RT_STACK_DEPTH - 16) * 4u)
+#define RT_STATIC_SCRATCH_BYTES (RT_FUSED_DEEP_OFFSET + (size_t)RT_STATIC_MAX_CUS * 8u * RT_BLOCK * (RT_WIDE_STACK_DEPTH - 16) * 4u)
 static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
 static std::atomic<void *> scratch_of_device[RT_STATIC_MAX_DEVICES];     // contexts may be created from several host threads
 

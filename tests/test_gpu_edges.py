@@ -441,10 +441,12 @@ def test_image_sides_beyond_16_bits_are_refused(ctx):
 
 def test_deep_tree_stack_beyond_its_lds_entries(ctx):
     """Spheres-only scenes with a tree deeper than 16 run the fused kernel with 16 stack entries
-    per lane in LDS and the rest in global memory.  200k nested spheres make every box contain the
-    centre, so a ray aimed there pushes one entry per level (18 levels) before its first leaf: the
-    image must be the one the wavefront pipeline (whole stack in LDS) gives, and first hits the
-    oracle's."""
+    per lane in LDS and the rest in global memory, on the four-children form of the tree (two
+    levels per node, up to three entries pushed per node).  200k nested spheres make every box
+    contain the centre, so a ray aimed there pushes entries at every level (18 levels of the binary
+    tree) before its first leaf: the image must be the one the wavefront pipeline (two-children
+    nodes, whole stack in LDS) gives, and the one of the fused kernel that walks the two-children
+    nodes because its caller brought no room for stack columns; first hits are the oracle's."""
     from raytracer_amd.renderer import NativeScene, Renderer, camera_rays
     n = 200_000
     cloud = scenes.SphereCloud(n, 9)
@@ -454,7 +456,7 @@ def test_deep_tree_stack_beyond_its_lds_entries(ctx):
     nat = NativeScene(ctx)
     cloud.encode(nat)
     nat.commit()
-    assert nat.stats()["bvh_depth"] > 16
+    assert nat.stats()["bvh_depth"] > 16 and nat.stats()["n_wide_nodes"] > 0
     a = Renderer(cloud, 192, 108, pipeline=abi.RT_PIPELINE_FUSED, ctx=ctx)
     b = Renderer(cloud, 192, 108, pipeline=abi.RT_PIPELINE_WAVEFRONT, ctx=ctx)
     for r in (a, b):

@@ -10,7 +10,9 @@ cp $G/${T}_wavefront_cfg2_64spp_kernel_stats.csv $P/${N}_wavefront_cfg2_64spp_ke
 cp $G/wavefront_traffic_cfg2_random_spheres_1080p_$T.json $P/${N}_wavefront_traffic_cfg2_64spp.json
 cp $G/bench_small_launches_$T.jsonl $P/${N}_bench_small_launches.jsonl
 cp $G/bench_cfg5_full_$T.json $P/${N}_bench_cfg5_full_1024spp_per_gpu.json
-cp $G/bench_cfg5_plain_$T.json $P/${N}_bench_cfg5_64spp_without_lds_top.json
+cp $G/bench_cfg5_64spp_$T.json $P/${N}_bench_cfg5_64spp.json
+cp $G/bench_cfg5_binary_$T.json $P/${N}_bench_cfg5_64spp_two_children_nodes.json
+cp $G/bench_cfg5_plain_$T.json $P/${N}_bench_cfg5_64spp_two_children_nodes_without_lds_top.json
 cp $G/interactive_fps_$T.txt $P/${N}_interactive_fps.txt
 for w in cfg2_random_spheres_1080p cfg3_cornell_smoke_1080p cfg4_csg_textured_1080p cfg5_sphere_cloud_4k; do
   cp $G/pmc_sq_${w}_$T.json $P/${N}_pmc_sq_$w.json

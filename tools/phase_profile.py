@@ -4,7 +4,7 @@ diagnostic build of the kernel, RT_OPTION_PROFILE_PHASES; its run time is not me
 usage (GPU box): python tools/phase_profile.py <workload> <spp> [executed.json]
 
 For a spheres-only workload the counters also price the work the kernel EXECUTES per sample
-(its own tree, nearest child first): node visits x two box tests + sphere tests + the shading,
+(its own tree, nearest child first): node visits x two (or four) box tests + sphere tests + the shading,
 ray generation and accumulation of the algorithmic count.  Written to the third argument as
 the record bench.py quotes beside the algorithmic fraction (profiles/executed_<workload>.json)."""
 import json
@@ -45,13 +45,15 @@ if len(sys.argv) > 3 and os.path.exists(fixture):
     n = float(cnt["samples"])
     shade = (sum(cnt["shades"][k] * f for k, f in roofline.F_SHADE.items()) + cnt["hits"] * roofline.F_HIT) / n
     nodes, leaves = pc[2, 1] / samples, pc[3, 1] / samples
-    executed = (roofline.F_RAYGEN + roofline.F_ACCUM + shade + nodes * 2 * roofline.F_BOX + object_flops / samples
+    # the render kernel walks the four-children form when the scene has one, unless the environment asks otherwise
+    boxes_per_visit = 4 if st["n_wide_nodes"] and not (_os.environ.get("RT_DEEP_BINARY") or _os.environ.get("RT_DEEP_PLAIN")) else 2
+    executed = (roofline.F_RAYGEN + roofline.F_ACCUM + shade + nodes * boxes_per_visit * roofline.F_BOX + object_flops / samples
                 + list_boxes / samples * roofline.F_BOX / 2)
     json.dump({"workload": name, "spp": spp, "node_visits_per_sample": nodes, "object_tests_per_sample": leaves,
                "object_test_flops_per_sample": object_flops / samples, "list_box_tests_per_sample": list_boxes / samples,
-               "shade_flops_per_sample": shade, "executed_flops_per_sample": executed,
+               "shade_flops_per_sample": shade, "executed_flops_per_sample": executed, "box_tests_per_node_visit": boxes_per_visit,
                "note": "phase counters of the diagnostic k_fused build (tools/phase_profile.py): lanes that took part in node steps "
-                       "(a node visit is two box tests) and object tests, each object test priced by the kinds of primitive it "
+                       "(a node visit is box_tests_per_node_visit box tests) and object tests, each object test priced by the kinds of primitive it "
                        "computes intervals of (roofline.py constants; a CSG shape: its leaves + two merge events per leaf); "
                        "shading from the oracle's event counts"}, open(sys.argv[3], "w"), indent=1)
     print("executed flops per sample %.1f" % executed)

@@ -29,6 +29,8 @@ cp gpurun_out/wfprof_$TAG/*/*kernel_stats.csv gpurun_out/${TAG}_wavefront_cfg2_6
 bash tools/wavefront_traffic.sh cfg2_random_spheres_1080p 64 $TAG > /dev/null
 echo "wavefront done"
 timeout -k 10 300 python bench.py --workload cfg5_sphere_cloud_4k --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_cfg5_full_$TAG.json 2>/dev/null
+timeout -k 10 200 python bench.py --workload cfg5_sphere_cloud_4k --spp 64 --steps 3 --warmup 1 > gpurun_out/bench_cfg5_64spp_$TAG.json 2>/dev/null
+RT_DEEP_BINARY=1 timeout -k 10 200 python bench.py --workload cfg5_sphere_cloud_4k --spp 64 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_cfg5_binary_$TAG.json 2>/dev/null
 RT_DEEP_PLAIN=1 timeout -k 10 200 python bench.py --workload cfg5_sphere_cloud_4k --spp 64 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_cfg5_plain_$TAG.json 2>/dev/null
 timeout -k 10 200 python tools/interactive_fps.py > gpurun_out/interactive_fps_$TAG.txt 2>&1
 echo "cfg5 and interactive done"
