@@ -291,8 +291,9 @@ int rt_scene_stats(const RtScene *, RtSceneStats *out);
  * (RayTracingKit/Hittable.swift:609-631), RT_BVH_SAH (default) a binned surface-area
  * heuristic; hit results do not depend on the choice.  RT_OPTION_REFILL_THRESHOLD: how many
  * lanes of a wave must be waiting before the fused kernel leaves its traversal loop (1..64; left
- * unset, each kernel uses its own: 48, and 28 for the kernel of trees deeper than 16 levels).
- * RT_OPTION_NODE_MIN: below how many lanes on inner nodes the kernel turns to waiting leaf tests.
+ * unset, each kernel uses its own: 48, and 24 for the kernel of trees deeper than 16 levels).
+ * RT_OPTION_NODE_MIN: below how many lanes on inner nodes the kernel turns to waiting leaf tests
+ * (0..64; left unset: 8, and 40 for the kernel of trees deeper than 16 levels).
  * RT_OPTION_NODE_FORMAT (before commit): how rt_render's fused kernel reads BVH nodes.
  * RT_NODES_F16 stores the child boxes as halves rounded outward (32-byte nodes, half the
  * fetch work; boxes only cull, so hits are the same), RT_NODES_F32 keeps the 64-byte nodes,
@@ -400,7 +401,7 @@ int rt_render(RtScene *, const RtCameraConfig *, const RtRenderConfig *, uint32_
  * No counterpart in the reference.  It is for callers that cannot allocate device memory or
  * call anything that might: code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc.  The kernel's scratch (work counter, camera, deep traversal-stack columns:
- * 16 MiB + 4 KiB) is an array inside the library, one copy per GPU, resolved when
+ * 40 MiB + 4 KiB) is an array inside the library, one copy per GPU, resolved when
  * rt_context_create runs on that GPU and held until the process ends.  The call itself makes no
  * hipMalloc / hipFree, creates no events (rt_kernel_time does not see it), never synchronises and
  * asks the runtime for nothing but the current device (hipGetDevice, and hipSetDevice there and back

@@ -3,6 +3,7 @@
 set -e
 T=$1; N=$2; G=gpurun_out; P=profiles
 cp $G/prof_$T.json $P/${N}_bench_cfg2.json
+cp $G/prof_nobase_$T.json $P/${N}_bench_cfg2_profiled_command.json     # the line of the run the kernel stats were taken from
 cp $G/${T}_bench_all_workloads_64spp.jsonl $P/${N}_bench_all_workloads_64spp.jsonl
 for f in $G/${T}_fused_*kernel_stats.csv; do b=$(basename $f); cp $f $P/${N}_${b#${T}_}; done
 cp $G/bench_wavefront_cfg2_$T.json $P/${N}_bench_wavefront_cfg2_64spp.json

@@ -5,8 +5,11 @@ set -e
 TAG=${1:-cur}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_$TAG
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py > gpurun_out/prof_$TAG.json 2> gpurun_out/prof_$TAG.err
+# (the profiled command leaves the CPU baseline out: its parity leg renders the baseline's sample on the GPU with the same
+# kernel, and those short launches would enter the kernel's average)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_nobase_$TAG.json 2> gpurun_out/prof_$TAG.err
 cp gpurun_out/prof_$TAG/*/*kernel_stats.csv gpurun_out/${TAG}_fused_cfg2_1024spp_kernel_stats.csv
+timeout -k 10 300 python bench.py > gpurun_out/prof_$TAG.json 2>> gpurun_out/prof_$TAG.err
 echo "kernel trace done"
 bash tools/measure_traffic.sh cfg2_random_spheres_1080p 1024 $TAG > /dev/null
 bash tools/measure_traffic.sh cfg5_sphere_cloud_4k 16 $TAG > /dev/null
