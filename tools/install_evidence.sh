@@ -1,5 +1,5 @@
-# Copies the files one run of tools/profile_round.sh <tag> left under gpurun_out/ into profiles/ under the names
-# DESIGN.md cites.  usage: bash tools/install_evidence.sh <tag> <name-prefix>   (e.g. r3z r3)
+# Copies the files one run of tools/profile_round.sh <tag> left under gpurun_out/ into profiles/ under the names the
+# design notes cite.  usage: bash tools/install_evidence.sh <tag> <name-prefix>   (e.g. r3z r3)
 set -e
 T=$1; N=$2; G=gpurun_out; P=profiles
 cp $G/prof_$T.json $P/${N}_bench_cfg2.json
