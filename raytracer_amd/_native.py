@@ -81,8 +81,8 @@ def _load():
     for name in EXPORTS:
         fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
         fn.restype, fn.argtypes = sig[name]
-    if L.rt_abi_version() != 2:
-        raise ImportError("libraytracer_amd.so has ABI version %d, expected 2" % L.rt_abi_version())
+    if L.rt_abi_version() != 3:
+        raise ImportError("libraytracer_amd.so has ABI version %d, expected 3" % L.rt_abi_version())
     return L
 
 

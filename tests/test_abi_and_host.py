@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_native.EXPORTS) == declared
     for name in declared:
         assert hasattr(_native.lib, name), name
-    assert _native.lib.rt_abi_version() == 2
+    assert _native.lib.rt_abi_version() == 3
 
 
 def test_record_sizes_match_the_reference_layout():
