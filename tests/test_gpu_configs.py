@@ -104,6 +104,8 @@ def test_million_spheres_first_hits(ctx, million):
     cloud, nat, orc, depth, seed = million
     st = nat.stats()
     assert st["n_objects"] == 1_000_000 and st["n_nodes"] == 999_999 and st["bvh_depth"] <= 24
+    # the four-children form the render kernel walks: every node but the last levels' holds 3-4 children
+    assert 999_999 // 3 <= st["n_wide_nodes"] <= 999_999 // 2
     grid = camera_rays(ctx, cloud.camera, RenderConfig(1, 1, 1, seed, 0), 160, 90)
     diag = np.concatenate([camera_rays(ctx, cloud.camera, RenderConfig(2, 1, 1, seed, 0), 3840, 2160, window=(24 * k, 13 * k + 7, 24, 1))
                            for k in range(0, 160, 3)])
@@ -135,7 +137,7 @@ def test_million_spheres_4k_pass(ctx, million):
     cloud, nat, orc, depth, seed = million
     w, h = 3840, 2160
     r = Renderer(cloud, w, h, native=nat)
-    assert r.native.stats()["bvh_depth"] > 16          # the deep-stack kernel is the one that runs
+    assert r.native.stats()["bvh_depth"] > 16 and r.native.stats()["n_wide_nodes"] > 0    # the deep-tree kernel is the one that runs
     r.draw(1, depth, seed)
     r.draw(1, depth, seed)
     two = Renderer(cloud, w, h, native=nat)

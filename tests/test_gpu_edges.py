@@ -103,6 +103,7 @@ def test_bvh_builders_give_identical_hits(ctx):
     assert same.mean() > 0.9999        # only exact ties between two objects may differ
     assert np.array_equal(ha["t"][same], hb["t"][same])
     assert b.stats()["bvh_depth"] <= 8 and a.stats()["n_nodes"] == b.stats()["n_nodes"]
+    assert a.stats()["n_wide_nodes"] == 0 and b.stats()["n_wide_nodes"] == 0       # shallow trees keep two children per node
 
 
 @pytest.mark.parametrize("make", [lambda: scenes.random_spheres(1), lambda: scenes.csg_textured(7), scenes.cornell_smoke,
